@@ -1,0 +1,167 @@
+"""FisheyeCalibrator: lens model holder + per-frame map generation, on MI355X.
+
+Host-side mirror of the hot-path part of the reference class of the same name
+(/root/reference/calibrate_video.py:33): preset loading (:520-587, :642-652) and get_maps (:330-384).
+The chessboard calibration itself (cv2.fisheye.calibrate, :137-259) is out of scope.
+
+get_maps() keeps the reference signature and returns the same (map1, map2) pair -- as CUDA tensors -- by calling
+libgfremap's map kernels; frame_xform()/frame_xforms() expose the same per-frame parameters for the fused
+kernel that never materialises the maps.
+"""
+import json
+
+import numpy as np
+from scipy.spatial.transform import Rotation
+
+from . import _lib, cv
+
+__version__ = "0.3.0-beta"      # preset compatibility tag of the reference (_version.py)
+
+
+def _quat_to_R(quat):
+    """(w,x,y,z) -> 3x3 with the reference's axis flips (calibrate_video.py:351-356)."""
+    q = np.asarray(quat, dtype=np.float64).flatten()
+    R = Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix()
+    R[[0, 0, 1, 2], [1, 2, 0, 0]] *= -1
+    return R
+
+
+class FisheyeCalibrator:
+    def __init__(self, chessboard_size=(9, 6)):
+        self.chessboard_size = chessboard_size
+        self.orig_dimension = np.array([0, 0])     # equal to calib_dimension when the footage is not stretched
+        self.calib_dimension = np.array([0, 0])
+        self.K = np.zeros((3, 3))
+        self.D = np.zeros((4, 1))
+        self.RMS_error = 100
+        self.input_horizontal_stretch = 1
+        self.data_from_preset_file = False
+        self.extra_cam_info = None
+        self.num_images = 0
+        self.num_images_used = 0
+        self.new_K = None
+
+    # ------------------------------------------------------------------ stretch helpers (:96-116)
+    def set_horizontal_stretch(self, new_stretch=1):
+        self.input_horizontal_stretch = new_stretch
+
+    def image_is_stretched(self):
+        return self.input_horizontal_stretch != 1
+
+    def get_stretched_size_from_dimension(self, new_img_dim):
+        return (round(new_img_dim[0] * self.calib_dimension[0] / self.orig_dimension[0]),
+                round(new_img_dim[1] * self.calib_dimension[1] / self.orig_dimension[1]))
+
+    # ------------------------------------------------------------------ presets (:520-587, :642-652)
+    def load_calibration_data(self, cal_data, printinfo=False):
+        try:
+            if not cal_data["use_opencv_fisheye"]:
+                raise Exception("Preset not for OpenCV fisheye lens model")
+            self.data_from_preset_file = True
+            if printinfo:
+                print("Preset name: {}".format(cal_data["name"]))
+                print("Note: {}".format(cal_data["note"]))
+                print("Made with {} frames using calibrator version {} on date {}".format(
+                    cal_data["num_images"], cal_data["calibrator_version"], cal_data["date"]))
+            if cal_data["calibrator_version"] != __version__ and printinfo:
+                print("Note: Versions don't match. Calibrator: {}, Preset: {}. Should be fine though.".format(
+                    __version__, cal_data["calibrator_version"]))
+
+            self.calib_dimension = (cal_data["calib_dimension"]["w"], cal_data["calib_dimension"]["h"])
+            if "orig_dimension" in cal_data:      # added in preset format 0.3.0
+                self.input_horizontal_stretch = cal_data["input_horizontal_stretch"]
+                self.orig_dimension = (cal_data["orig_dimension"]["w"], cal_data["orig_dimension"]["h"])
+            else:
+                self.input_horizontal_stretch = 1
+                self.orig_dimension = self.calib_dimension
+
+            self.num_images = self.num_images_used = cal_data["num_images"]
+            self.RMS_error = cal_data["fisheye_params"]["RMS_error"]
+            self.K = np.array(cal_data["fisheye_params"]["camera_matrix"])
+            self.D = np.array(cal_data["fisheye_params"]["distortion_coeffs"])
+
+            fixed_name = " ".join(cal_data.get("name").replace("_", " ").split())
+            self.extra_cam_info = {
+                "name": fixed_name,
+                "note": cal_data.get("note"),
+                "calibrated_by": cal_data.get("calibrated_by", "N/A"),
+                "camera_brand": cal_data.get("camera_brand", "N/A"),
+                "camera_model": cal_data.get("camera_model", "N/A"),
+                "camera_setting": cal_data.get("camera_setting", "N/A"),
+                "lens_model": cal_data.get("lens_model", "N/A"),
+                "calibrator_version": cal_data.get("calibrator_version"),
+                "date": cal_data.get("date"),
+                "width": self.orig_dimension[0],
+                "height": self.orig_dimension[1],
+                "aspect": self.orig_dimension[0] / self.orig_dimension[1],
+                "num_images": self.num_images,
+            }
+        except ZeroDivisionError:
+            raise KeyError("Error loading preset file")
+        return self.extra_cam_info
+
+    def load_calibration_json(self, filename, printinfo=False):
+        with open(filename, "r") as infile:
+            presets = json.load(infile)
+        return self.load_calibration_data(presets, printinfo)
+
+    # ------------------------------------------------------------------ per-frame parameters (:341-370)
+    def _frame_matrices(self, fov_scale, output_dim, new_img_dim, quat, focalCenter, original_stretched):
+        """The (scaled_K, D, R, new_K, out_dim) the reference hands to cv2.fisheye.initUndistortRectifyMap."""
+        if new_img_dim and self.image_is_stretched() and original_stretched:
+            # new_img_dim is the size of the unstretched video frame
+            new_img_dim = (round(new_img_dim[0] * self.calib_dimension[0] / self.orig_dimension[0]),
+                           round(new_img_dim[1] * self.calib_dimension[1] / self.orig_dimension[1]))
+        img_dim = new_img_dim if new_img_dim else self.calib_dimension
+        out_dim = output_dim if output_dim else self.calib_dimension
+        if focalCenter is None:
+            focalCenter = np.array([self.calib_dimension[0] / 2, self.calib_dimension[1] / 2])
+
+        R = np.eye(3) if quat is None else _quat_to_R(quat)
+
+        img_dim_ratio = img_dim[0] / self.calib_dimension[0]
+        scaled_K = self.K * img_dim_ratio
+        scaled_K[2][2] = 1.0
+
+        new_K = np.copy(self.K)
+        new_K[0][0] = new_K[0][0] * 1.0 / fov_scale
+        new_K[1][1] = new_K[1][1] * 1.0 / fov_scale
+        new_K[0][2] = (self.calib_dimension[0] / 2 - focalCenter[0]) * img_dim_ratio / fov_scale + out_dim[0] / 2
+        new_K[1][2] = (self.calib_dimension[1] / 2 - focalCenter[1]) * img_dim_ratio / fov_scale + out_dim[1] / 2
+        return scaled_K, self.D, R, new_K, (int(out_dim[0]), int(out_dim[1]))
+
+    def get_maps(self, fov_scale=1.0, output_dim=None, new_img_dim=None, update_new_K=True, quat=None,
+                 focalCenter=None, original_stretched=True, device=None):
+        """Undistortion + rotation maps for one frame (reference: calibrate_video.py:330).
+
+        Returns (map1 int16[H,W,2], map2 uint16[H,W]) CUDA tensors in cv2's CV_16SC2 / CV_16UC1 fixed-point layout."""
+        scaled_K, D, R, new_K, out_dim = self._frame_matrices(fov_scale, output_dim, new_img_dim, quat, focalCenter,
+                                                             original_stretched)
+        if update_new_K:
+            self.new_K = new_K
+        if original_stretched and self.image_is_stretched():
+            fx, fy = cv.fisheye_initUndistortRectifyMap(scaled_K, D, R, new_K, out_dim, cv.CV_32FC1, device=device)
+            # rescale to the stretched video's pixel grid, then to fixed point (float32, as numpy does it at :378)
+            return cv.convertMaps(fx, fy, cv.CV_16SC2,
+                                  scale_x=(self.orig_dimension[0], self.calib_dimension[0]),
+                                  scale_y=(self.orig_dimension[1], self.calib_dimension[1]))
+        return cv.fisheye_initUndistortRectifyMap(scaled_K, D, R, new_K, out_dim, cv.CV_16SC2, device=device)
+
+    # ------------------------------------------------------------------ fused-path parameters
+    def frame_xform(self, fov_scale=1.0, output_dim=None, new_img_dim=None, quat=None, focalCenter=None):
+        """One gf_frame_xform row (17 float64) for cv.undistort_rotate: same parameters as get_maps()."""
+        if self.image_is_stretched():
+            raise NotImplementedError("stretched presets go through get_maps() + remap() (float32 map rescale)")
+        scaled_K, D, R, new_K, _ = self._frame_matrices(fov_scale, output_dim, new_img_dim, quat, focalCenter, True)
+        return _lib.xform_to_array(_lib.make_frame_xform(scaled_K, D, R, new_K))
+
+    def frame_xforms(self, fov_scales, quats, output_dim=None, new_img_dim=None, focalCenters=None):
+        """[N,17] float64: frame_xform() for every (fov_scale[i], quat[i], focalCenter[i])."""
+        quats = np.asarray(quats, np.float64)
+        n = quats.shape[0]
+        fov_scales = np.broadcast_to(np.asarray(fov_scales, np.float64), (n,))
+        out = np.empty((n, _lib.XFORM_DOUBLES), np.float64)
+        for i in range(n):
+            fc = None if focalCenters is None else focalCenters[i]
+            out[i] = self.frame_xform(float(fov_scales[i]), output_dim, new_img_dim, quats[i], fc)
+        return out

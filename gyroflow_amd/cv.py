@@ -1,0 +1,280 @@
+"""The slice of the cv2 call surface that gyroflow's hot path uses, running on MI355X through libgfremap.so.
+
+Mirrors (names, argument meaning, return/ownership rules):
+  cv2.fisheye.initUndistortRectifyMap   /root/reference/calibrate_video.py:322,376,383
+  cv2.convertMaps                       /root/reference/calibrate_video.py:378
+  cv2.remap                             /root/reference/stabilizer.py:1442, nonlinear_stretch.py:130, gyroflow.py:275,283
+
+Arrays may be torch CUDA tensors (stay on the device, work is enqueued on torch's current stream) or numpy
+arrays (uploaded, processed on cuda:<current>, downloaded: numpy in -> numpy out, like cv2).  There is no CPU
+implementation behind these functions.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+CV_32FC1 = 5
+CV_16SC2 = 11
+INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
+BORDER_CONSTANT, BORDER_REPLICATE, BORDER_TRANSPARENT = 0, 1, 5
+
+_vp = C.c_void_p
+
+
+def _device(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("gyroflow_amd needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU path")
+    if device is None:
+        return torch.device("cuda", torch.cuda.current_device())
+    device = torch.device(device)
+    if device.type != "cuda":
+        raise ValueError("device must be a cuda device")
+    return torch.device("cuda", torch.cuda.current_device() if device.index is None else device.index)
+
+
+def _stream(dev):
+    return _vp(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _to_dev(a, dev):
+    """-> (cuda tensor, came_from_numpy)"""
+    if isinstance(a, torch.Tensor):
+        if a.device.type != "cuda":
+            return a.to(dev), False
+        return a, False
+    a = np.asarray(a)
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev), True
+
+
+def _ptr(t):
+    return _vp(t.data_ptr())
+
+
+def _depth(t):
+    if t.dtype == torch.uint8:
+        return _lib.DEPTH_U8
+    if t.dtype == torch.uint16:
+        return _lib.DEPTH_U16
+    raise TypeError("only uint8 / uint16 images are supported, got %s" % t.dtype)
+
+
+def _check_img(t, what):
+    if t.dim() != 3 or t.shape[2] != 3:
+        raise ValueError("%s must be HxWx3, got %s" % (what, tuple(t.shape)))
+    if t.stride(2) != 1 or t.stride(1) != 3:
+        raise ValueError("%s must have packed pixels (row stride may be padded)" % what)
+
+
+def fisheye_initUndistortRectifyMap(K, D, R, P, size, m1type, device=None):
+    """cv2.fisheye.initUndistortRectifyMap(K, D, R, P, size, m1type) -> (map1, map2) as CUDA tensors.
+
+    m1type CV_16SC2 -> int16[H,W,2] + uint16[H,W];  CV_32FC1 -> float32[H,W] x 2."""
+    dev = _device(device)
+    w, h = int(size[0]), int(size[1])
+    xf = _lib.make_frame_xform(K, D, R, P)
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        if m1type == CV_16SC2:
+            m1 = torch.empty((h, w, 2), dtype=torch.int16, device=dev)
+            m2 = torch.empty((h, w), dtype=torch.uint16, device=dev)
+            _lib.check(lib.gf_fisheye_maps_16sc2(ctx, C.byref(xf), w, h, _ptr(m1), w * 4, _ptr(m2), w * 2, _stream(dev)))
+        elif m1type == CV_32FC1:
+            m1 = torch.empty((h, w), dtype=torch.float32, device=dev)
+            m2 = torch.empty((h, w), dtype=torch.float32, device=dev)
+            _lib.check(lib.gf_fisheye_maps_32f(ctx, C.byref(xf), w, h, _ptr(m1), w * 4, _ptr(m2), w * 4, _stream(dev)))
+        else:
+            raise ValueError("m1type must be CV_16SC2 or CV_32FC1")
+    return m1, m2
+
+
+def convertMaps(map1, map2, dstmap1type=CV_16SC2, scale_x=None, scale_y=None):
+    """cv2.convertMaps(map1_f32, map2_f32, cv2.CV_16SC2).
+
+    scale_x=(num, den) / scale_y=(num, den) fold in the reference's float32 pre-scaling
+    `map1 * orig_w / calib_w` (calibrate_video.py:378): multiply, round, divide, round -- in float32."""
+    if dstmap1type != CV_16SC2:
+        raise ValueError("only CV_16SC2 output is supported")
+    dev = _device(map1.device if isinstance(map1, torch.Tensor) and map1.is_cuda else None)
+    m1, np1 = _to_dev(map1, dev)
+    m2, _ = _to_dev(map2, dev)
+    if m1.dtype != torch.float32 or m2.dtype != torch.float32 or m1.shape != m2.shape or m1.dim() != 2:
+        raise ValueError("maps must be two float32 HxW arrays")
+    m1 = m1.contiguous(); m2 = m2.contiguous()
+    h, w = m1.shape
+    sx = (1.0, 1.0) if scale_x is None else scale_x
+    sy = (1.0, 1.0) if scale_y is None else scale_y
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        o1 = torch.empty((h, w, 2), dtype=torch.int16, device=dev)
+        o2 = torch.empty((h, w), dtype=torch.uint16, device=dev)
+        _lib.check(lib.gf_convert_maps_32f_16sc2(ctx, _ptr(m1), w * 4, _ptr(m2), w * 4, float(sx[0]), float(sx[1]),
+                                                 float(sy[0]), float(sy[1]), w, h, _ptr(o1), w * 4, _ptr(o2), w * 2,
+                                                 _stream(dev)))
+    if np1:
+        return o1.cpu().numpy(), o2.cpu().numpy()
+    return o1, o2
+
+
+def remap(src, map1, map2, interpolation, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+    """cv2.remap for the two map/interpolation combinations the reference uses:
+       INTER_LINEAR with (int16[H,W,2], uint16[H,W]) maps on uint8/uint16 HxWx3, and
+       INTER_CUBIC  with (float32[H,W], float32[H,W]) maps on uint8 HxWx3.
+    Returns dst: the given dst is written in place when its shape/dtype match (as cv2 does), otherwise a new
+    zero-filled array is created."""
+    src_is_t = isinstance(src, torch.Tensor)
+    dev = _device(src.device if src_is_t and src.is_cuda else None)
+    s, s_np = _to_dev(src, dev)
+    _check_img(s, "src")
+    m1, _ = _to_dev(map1, dev)
+    m2, _ = _to_dev(map2, dev)
+    dh, dw = int(m2.shape[0]), int(m2.shape[1])
+    depth = _depth(s)
+
+    d, d_np, dst_ok = None, False, False
+    if dst is not None:
+        shape_ok = tuple(dst.shape) == (dh, dw, 3)
+        if isinstance(dst, torch.Tensor):
+            dst_ok = shape_ok and dst.dtype == s.dtype and dst.is_cuda and dst.device == s.device and dst.stride(2) == 1 and dst.stride(1) == 3
+            if dst_ok:
+                d = dst
+        else:
+            dst_ok = shape_ok and dst.dtype == (np.uint8 if depth == 0 else np.uint16) and dst.flags.c_contiguous
+            if dst_ok:
+                d_np = True
+                d = torch.from_numpy(dst).to(dev) if borderMode == BORDER_TRANSPARENT else \
+                    torch.empty((dh, dw, 3), dtype=s.dtype, device=dev)
+    if d is None:
+        d = torch.zeros((dh, dw, 3), dtype=s.dtype, device=dev)
+    esz = s.element_size()
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    bv = _lib.border_value(borderValue)
+    with torch.cuda.device(dev):
+        if interpolation == INTER_LINEAR:
+            if m1.dtype != torch.int16 or m1.dim() != 3 or m1.shape[2] != 2 or m2.dtype != torch.uint16 or tuple(m1.shape[:2]) != (dh, dw):
+                raise ValueError("INTER_LINEAR needs map1 int16[H,W,2] and map2 uint16[H,W]")
+            m1 = m1.contiguous(); m2 = m2.contiguous()
+            _lib.check(lib.gf_remap_linear_c3(ctx, depth, _ptr(s), s.shape[1], s.shape[0], s.stride(0) * esz,
+                                              _ptr(d), dw, dh, d.stride(0) * esz, _ptr(m1), dw * 4, _ptr(m2), dw * 2,
+                                              int(borderMode), bv, _stream(dev)))
+        elif interpolation == INTER_CUBIC:
+            if m1.dtype != torch.float32 or m2.dtype != torch.float32 or m1.shape != m2.shape or m1.dim() != 2:
+                raise ValueError("INTER_CUBIC needs two float32 HxW maps")
+            if depth != _lib.DEPTH_U8:
+                raise TypeError("INTER_CUBIC is implemented for uint8 only")
+            m1 = m1.contiguous(); m2 = m2.contiguous()
+            _lib.check(lib.gf_remap_cubic_u8c3_f32maps(ctx, _ptr(s), s.shape[1], s.shape[0], s.stride(0), _ptr(d), dw, dh,
+                                                       d.stride(0), _ptr(m1), dw * 4, _ptr(m2), dw * 4, int(borderMode), bv,
+                                                       _stream(dev)))
+        else:
+            raise ValueError("interpolation must be INTER_LINEAR or INTER_CUBIC")
+    if s_np or d_np:
+        out = d.cpu().numpy()
+        if d_np:
+            dst[...] = out
+            return dst
+        return out
+    return d
+
+
+def xforms_to_device(xforms, device=None):
+    """[N,17] float64 numpy (rows = gf_frame_xform) -> CUDA tensor for undistort_rotate()."""
+    dev = _device(device)
+    a = np.ascontiguousarray(np.asarray(xforms, np.float64).reshape(-1, _lib.XFORM_DOUBLES))
+    return torch.from_numpy(a).to(dev)
+
+
+def _frames4(t, what):
+    if t.dim() == 3:
+        t = t.unsqueeze(0)
+    if t.dim() != 4 or t.shape[3] != 3 or t.stride(3) != 1 or t.stride(2) != 3:
+        raise ValueError("%s must be [N,]HxWx3 with packed pixels" % what)
+    return t
+
+
+def undistort_rotate(src, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+    """Fused get_maps + remap(INTER_LINEAR) for a batch of frames (stabilizer.py:1423-1443 per frame).
+
+    src: CUDA uint8/uint16 [N,H,W,3] (or [H,W,3]; a stride-0 expand() over N reuses one input frame).
+    xforms_dev: CUDA float64 [N,17] from xforms_to_device().  Returns dst [N,out_h,out_w,3]."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda):
+        raise TypeError("undistort_rotate works on CUDA tensors")
+    dev = src.device
+    s = _frames4(src, "src")
+    n = s.shape[0]
+    if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
+        raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,17] tensor with N = number of frames")
+    dw, dh = int(out_size[0]), int(out_size[1])
+    if dst is None:
+        d = torch.zeros((n, dh, dw, 3), dtype=s.dtype, device=dev) if borderMode == BORDER_TRANSPARENT else \
+            torch.empty((n, dh, dw, 3), dtype=s.dtype, device=dev)
+    else:
+        d = _frames4(dst, "dst")
+        if tuple(d.shape) != (n, dh, dw, 3) or d.dtype != s.dtype or d.device != dev:
+            raise ValueError("dst has the wrong shape/dtype/device")
+    esz = s.element_size()
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gf_undistort_rotate_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
+                                              _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _ptr(xforms_dev), n,
+                                              int(borderMode), _lib.border_value(borderValue), _stream(dev)))
+    return d if (dst is None or dst.dim() == 4) else d[0]
+
+
+def undistort_rotate_blend(src, xforms_dev, out_size, frames_per_group, n_blend, dst=None,
+                           borderMode=BORDER_CONSTANT, borderValue=0):
+    """Fused remap + hyperlapse blend (stabilizer.py:1431-1447,1464-1468): output g is the truncated float64 mean of
+    the remaps of input frames g*frames_per_group .. +n_blend-1.  src [N_in,H,W,3], returns [n_out,out_h,out_w,3]."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda):
+        raise TypeError("undistort_rotate_blend works on CUDA tensors")
+    dev = src.device
+    s = _frames4(src, "src")
+    n_in = s.shape[0]
+    if n_blend < 1 or frames_per_group < n_blend or n_in < n_blend:
+        raise ValueError("need 1 <= n_blend <= frames_per_group and at least n_blend input frames")
+    n_out = (n_in - n_blend) // frames_per_group + 1
+    if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() < ((n_out - 1) * frames_per_group + n_blend) * _lib.XFORM_DOUBLES:
+        raise ValueError("xforms_dev must hold one transform per input frame")
+    dw, dh = int(out_size[0]), int(out_size[1])
+    d = torch.empty((n_out, dh, dw, 3), dtype=s.dtype, device=dev) if dst is None else _frames4(dst, "dst")
+    if tuple(d.shape) != (n_out, dh, dw, 3) or d.dtype != s.dtype:
+        raise ValueError("dst has the wrong shape/dtype")
+    esz = s.element_size()
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gf_undistort_rotate_blend_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
+                                                    _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _ptr(xforms_dev),
+                                                    n_out, int(frames_per_group), int(n_blend), int(borderMode),
+                                                    _lib.border_value(borderValue), _stream(dev)))
+    return d
+
+
+def blend_accumulate(frame, acc, weight, reset):
+    """acc (CUDA float64, same number of elements as frame) = (acc*0 if reset else acc) + weight*frame."""
+    dev = frame.device
+    f = frame.contiguous()
+    if acc.dtype != torch.float64 or acc.numel() != f.numel() or not acc.is_contiguous():
+        raise ValueError("acc must be a contiguous float64 tensor of frame's size")
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gf_blend_accumulate(ctx, _depth(f), _ptr(f), _ptr(acc), float(weight), int(bool(reset)), f.numel(), _stream(dev)))
+    return acc
+
+
+def blend_finalize(acc, dtype):
+    """numpy-style truncating astype(uint8/uint16) of the float64 accumulator."""
+    dev = acc.device
+    out = torch.empty(acc.shape, dtype=dtype, device=dev)
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gf_blend_finalize(ctx, _depth(out), _ptr(acc), _ptr(out), acc.numel(), _stream(dev)))
+    return out
+
+
+def cubic_table():
+    """Host copy of the library's 1024x16 int16 bicubic table (no GPU needed)."""
+    out = np.empty((1024, 16), np.int16)
+    _lib.check(_lib.load().gf_get_cubic_table(out.ctypes.data_as(_vp)))
+    return out

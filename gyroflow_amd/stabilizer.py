@@ -1,0 +1,271 @@
+"""Stabilizer: the render/export loop of the hot path, re-hosted on MI355X.
+
+Mirror of the render-path part of /root/reference/stabilizer.py: `set_hyperlapse` (:239-248), `map_function`
+(:1205-1215), `set_map_func_scale` (:1217) and `renderfile` (:1220-1531).  Video decode (cv2.VideoCapture) and
+encode (vidgear/ffmpeg) stay on the CPU and are abstracted as a frame source / sink so synthetic frames can drive the
+same loop; gyro parsing, integration, smoothing and optical-flow sync are out of scope -- the per-frame stabilisation
+quaternions `stab_transform` (w,x,y,z per video frame) are an input.
+
+Loop rules kept from the reference: the loop runs i = 1 .. num_frames-1 with
+num_frames = int((stop-start)*fps); frame_num is the source position *before* the read; a group of
+`hyperlapse_multiplier` frames contributes its first `hyperlapse_num_blended_frames` frames; the output frame is
+emitted on the group's last blended frame; rendering stops when frame_num runs past stab_transform or after more
+than five consecutive failed reads.
+"""
+import numpy as np
+import torch
+from matplotlib import colors
+
+from . import cv
+from .calibrate_video import FisheyeCalibrator
+from .pipeline import BatchPipeline
+
+
+# ----------------------------------------------------------------------------- frame sources / sinks
+class ArraySource:
+    """Frame source over an in-memory sequence of HxWx3 arrays (stands in for cv2.VideoCapture).
+    `ring=True` cycles the sequence so a few distinct frames can represent a long clip."""
+
+    def __init__(self, frames, count=None, ring=False, fail_at=()):
+        self.frames = frames
+        self.count = len(frames) if count is None else int(count)
+        self.ring = ring
+        self.pos = 0
+        self.fail_at = set(fail_at)
+
+    def get_pos(self):
+        return self.pos
+
+    def set_pos(self, n):
+        self.pos = int(n)
+
+    def read(self):
+        p = self.pos
+        if p >= self.count:
+            return False, None
+        self.pos += 1
+        if p in self.fail_at:
+            return False, None
+        return True, self.frames[p % len(self.frames) if self.ring else p]
+
+
+def synthetic_frames(width, height, n=8, dtype=np.uint8, seed=1234):
+    """Seeded synthetic BGR frames: smooth gradient + 16-px checkerboard + +-8 noise.
+    uint16 frames carry 10-bit values shifted left by 6."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:height, 0:width]
+    frames = []
+    for k in range(n):
+        base = np.stack([(xx * 255.0 / max(width - 1, 1) + 17 * k) % 256,
+                         (yy * 255.0 / max(height - 1, 1) + 29 * k) % 256,
+                         ((xx + yy) * 255.0 / max(width + height - 2, 1) + 43 * k) % 256], axis=-1)
+        checker = ((((xx // 16) + (yy // 16) + k) & 1) * 48.0)[..., None]
+        noise = rng.integers(-8, 9, size=(height, width, 3))
+        img = np.clip(base * 0.75 + checker + noise, 0, 255)
+        if np.dtype(dtype) == np.uint16:
+            frames.append((np.clip(img * 4.0 + rng.integers(0, 4, size=img.shape), 0, 1023).astype(np.uint16) << 6))
+        else:
+            frames.append(img.astype(np.uint8))
+    return frames
+
+
+class ListSink:
+    def __init__(self):
+        self.frames = []
+
+    def write(self, frame):
+        self.frames.append(np.array(frame, copy=True))
+
+    def close(self):
+        pass
+
+
+class NullSink:
+    """Counts frames and keeps a cheap checksum (sum of all bytes mod 2^64) instead of storing them."""
+
+    def __init__(self):
+        self.count = 0
+        self.checksum = 0
+
+    def write(self, frame):
+        self.count += 1
+        self.checksum = (self.checksum + int(frame[::16, ::16].astype(np.uint64).sum())) & 0xFFFFFFFFFFFFFFFF
+
+    def close(self):
+        pass
+
+
+# ----------------------------------------------------------------------------- the stabilizer
+class Stabilizer:
+    def __init__(self, source, calibration, stab_transform, fps, width, height, device=None):
+        """source: frame source; calibration: FisheyeCalibrator or preset path; stab_transform: [F,4] (w,x,y,z);
+        width/height: size of the video frames (`orig_dimension` in the reference)."""
+        self.cap = source
+        if isinstance(calibration, FisheyeCalibrator):
+            self.undistort = calibration
+        else:
+            self.undistort = FisheyeCalibrator()
+            self.undistort.load_calibration_json(calibration)
+        self.stab_transform = np.asarray(stab_transform, np.float64)
+        self.fps = fps
+        self.width, self.height = int(width), int(height)
+        self.orig_dimension = (self.width, self.height)
+        self.map_func_scale = 0.9
+        self.hyperlapse_multiplier = 1
+        self.hyperlapse_num_blended_frames = 1
+        self.hyperlapse_skipped_frames = 0
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.adaptive_zoom = None          # optional callable: (stab_transform, out_size, fps, smoothingFocus, tstart, tend) -> (fcorr, focalCenter)
+
+    def set_hyperlapse(self, hyperlapse_multiplier=1, hyperlapse_num_blended_frames=1):
+        # frames |0|1|2|3|4|5|6|7|...  mult=4, num_blend=2  ->  |0+1|4+5|...
+        self.hyperlapse_multiplier = hyperlapse_multiplier
+        self.hyperlapse_num_blended_frames = min(hyperlapse_multiplier, hyperlapse_num_blended_frames)
+        self.hyperlapse_skipped_frames = self.hyperlapse_multiplier - self.hyperlapse_num_blended_frames
+
+    def set_map_func_scale(self, map_scale=0.9):
+        self.map_func_scale = map_scale
+
+    def map_function(self, frame_num, out_size=(1280, 720), regenerate=False):
+        """Preview maps for one frame (reference :1205-1215): fixed-point (map1, map2) CUDA tensors."""
+        if frame_num >= len(self.stab_transform):
+            frame_num = len(self.stab_transform) - 1
+            print("No more stabilization data. Using last frame")
+        return self.undistort.get_maps(self.map_func_scale,
+                                       new_img_dim=(self.orig_dimension[0], self.orig_dimension[1]),
+                                       output_dim=out_size, update_new_K=False, quat=self.stab_transform[frame_num],
+                                       focalCenter=None, original_stretched=True, device=self.device)
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def border_from_bg_color(bg_color):
+        """reference :1235-1244"""
+        if bg_color == "REPLICATE":
+            return cv.BORDER_REPLICATE, 0
+        if bg_color == "HISTORY":
+            return cv.BORDER_TRANSPARENT, 0
+        return cv.BORDER_CONSTANT, [round(x * 255) for x in colors.to_rgb(bg_color)][::-1]
+
+    def _fov_terms(self, out_size, smoothingFocus, tstart, tend):
+        n = len(self.stab_transform)
+        if self.adaptive_zoom is not None:
+            fcorr, focal = self.adaptive_zoom(self.stab_transform, out_size, self.fps, smoothingFocus, tstart, tend)
+            return np.asarray(fcorr, np.float64), np.asarray(focal, np.float64)
+        cd = self.undistort.calib_dimension
+        return np.ones(n), np.tile(np.array([cd[0] / 2, cd[1] / 2], np.float64), (n, 1))
+
+    def _xform(self, fov, frame_num, out_size, focal):
+        return self.undistort.frame_xform(fov, output_dim=out_size, new_img_dim=self.orig_dimension,
+                                          quat=self.stab_transform[frame_num], focalCenter=focal)
+
+    # ------------------------------------------------------------------ render loop
+    def renderfile(self, starttime, stoptime, sink, out_size=(1920, 1080), fov_scale=1.0, smoothingFocus=-2,
+                   bg_color="#000000", batch=8, pipeline_depth=2, sequential=False):
+        """Render [starttime, stoptime) through the fused undistort+rotate kernel into `sink`.
+
+        Returns the number of frames written.  `sequential=True` (always used for bg_color="HISTORY", stretched
+        presets and after a failed read) issues the reference's per-frame sequence get_maps -> remap -> blend;
+        otherwise frames are batched through the pinned three-stream pipeline and the fused kernels."""
+        borderMode, borderValue = self.border_from_bg_color(bg_color)
+        num_frames = int((stoptime - starttime) * self.fps)
+        tstart = int(starttime * self.fps)
+        tend = tstart + num_frames
+        fcorr, focalCenter = self._fov_terms(out_size, smoothingFocus, tstart, tend)
+
+        self.cap.set_pos(int(starttime * self.fps))
+        mult, nblend = self.hyperlapse_multiplier, self.hyperlapse_num_blended_frames
+        if borderMode == cv.BORDER_TRANSPARENT or self.undistort.image_is_stretched():
+            sequential = True
+
+        written = [0]
+
+        def emit(frames):
+            for f in frames:
+                sink.write(f)
+                written[0] += 1
+
+        dtype = None
+        pipe = None
+        pend_frames, pend_xf = [], []          # frames of complete/incomplete groups waiting for a batch
+        seq = None                              # state of the sequential path
+
+        def flush_batch():
+            nonlocal pend_frames, pend_xf
+            n_groups = len(pend_frames) // nblend
+            if n_groups == 0:
+                return
+            n = n_groups * nblend
+            frames, xf = pend_frames[:n], np.stack(pend_xf[:n])
+            pend_frames, pend_xf = pend_frames[n:], pend_xf[n:]
+            xf_dev = cv.xforms_to_device(xf, self.device)
+
+            def launch(din, dout):
+                if nblend == 1:
+                    cv.undistort_rotate(din, xf_dev, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue)
+                else:
+                    cv.undistort_rotate_blend(din, xf_dev, out_size, nblend, nblend, dst=dout[:n_groups],
+                                              borderMode=borderMode, borderValue=borderValue)
+                return n_groups
+            pipe.submit(frames, launch)
+
+        num_not_success, num_not_success_lim = 0, 5
+        for i in range(1, num_frames):
+            frame_num = int(self.cap.get_pos())
+            success, frame = self.cap.read()
+            if success:
+                num_not_success = 0
+            elif num_not_success >= num_not_success_lim:
+                print("Unable to read multiple frames")
+                break
+            else:
+                num_not_success += 1
+            if frame_num >= len(self.stab_transform):
+                print("No more stabilization data. Stopping render here.")
+                break
+            if not success:
+                if not sequential and nblend > 1:
+                    # a hole inside a blend group: finish this clip in the reference's per-frame order
+                    raise NotImplementedError("failed read inside a hyperlapse blend group: render with sequential=True")
+                continue
+
+            phase = (i - 1) % mult
+            if dtype is None:
+                dtype = torch.uint8 if frame.dtype == np.uint8 else torch.uint16
+            fov = fov_scale * fcorr[frame_num]
+
+            if sequential:
+                if seq is None:
+                    seq = dict(frame_out=None, frame_temp=torch.zeros((out_size[1], out_size[0], 3), dtype=torch.float64, device=self.device))
+                reset = phase == 0 and nblend > 1          # frame_temp * 0.0 at the start of a hyperlapse group
+                if phase < nblend:
+                    m1, m2 = self.undistort.get_maps(fov, new_img_dim=self.orig_dimension, output_dim=out_size,
+                                                     update_new_K=False, quat=self.stab_transform[frame_num],
+                                                     focalCenter=focalCenter[frame_num], device=self.device)
+                    src = torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
+                    seq["frame_out"] = cv.remap(src, m1, m2, cv.INTER_LINEAR, dst=seq["frame_out"], borderMode=borderMode,
+                                                borderValue=borderValue)
+                    if nblend > 1:
+                        cv.blend_accumulate(seq["frame_out"], seq["frame_temp"], 1 / nblend, reset)
+                if (phase - nblend + 1) % mult == 0 and seq["frame_out"] is not None:
+                    if nblend > 1:
+                        seq["frame_out"] = cv.blend_finalize(seq["frame_temp"], dtype)
+                    emit([seq["frame_out"].cpu().numpy()])
+                continue
+
+            if phase < nblend:
+                if pipe is None:
+                    out_batch = batch if nblend == 1 else max(1, batch // nblend)
+                    in_batch = out_batch * nblend
+                    pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (out_size[1], out_size[0]), dtype,
+                                         in_batch, emit, depth=pipeline_depth, out_batch=out_batch)
+                pend_frames.append(frame)
+                pend_xf.append(self._xform(fov, frame_num, out_size, focalCenter[frame_num]))
+                if len(pend_frames) >= pipe.batch:
+                    flush_batch()
+
+        if pipe is not None:
+            flush_batch()          # complete groups only; an unfinished trailing group emits nothing (as in the reference)
+            pipe.flush()
+        sink.close()
+        print("Render finished")
+        return written[0]

@@ -1,0 +1,144 @@
+/*
+ * gfremap.h -- C ABI of libgfremap.so: the MI355X (gfx950) implementation of gyroflow's per-frame
+ * fisheye-undistort + rotation remap hot path.
+ *
+ * The reference (ElvinC/gyroflow, legacy Python) has no FFI for this path: it calls opencv-python
+ * from Python.  Each entry point below therefore cites the Python call site (file:line under the
+ * reference tree) whose arithmetic it replaces; the Python modules under gyroflow_amd/ keep the reference's Python call
+ * surface on top of this ABI (INTEGRATION.md shows the ctypes binding a maintainer would add).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes only.  Pointers are DEVICE pointers unless the name ends
+ *     in _host or the comment says "host"; the caller owns every buffer; *_step are row strides in BYTES.
+ *   - Every call returns GF_OK (0) or a negative GF_ERR_* and never throws/aborts;
+ *     gf_last_error() returns a thread-local message for the last failure on this thread.
+ *   - Work is enqueued on the caller's hipStream_t (passed as void*; NULL = default stream) and is
+ *     asynchronous; nothing here synchronises, allocates or frees device memory (gf_ctx_create
+ *     uploads two small constant tables once).
+ *   - Images are interleaved 3-channel (BGR/RGB order is irrelevant to the arithmetic), depth
+ *     GF_DEPTH_U8 or GF_DEPTH_U16.  All image dimensions must be < 32767 (cv::remap's own assert).
+ */
+#ifndef GFREMAP_H
+#define GFREMAP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define GF_API __attribute__((visibility("default")))
+#else
+#define GF_API
+#endif
+
+#define GF_VERSION 100
+
+#define GF_OK               0
+#define GF_ERR_INVALID_ARG -1
+#define GF_ERR_HIP         -2
+#define GF_ERR_UNSUPPORTED -3
+#define GF_ERR_SINGULAR    -4
+
+/* cv2 depth codes */
+#define GF_DEPTH_U8  0   /* CV_8U  */
+#define GF_DEPTH_U16 2   /* CV_16U */
+
+/* cv2 border codes as the reference selects them (stabilizer.py:1235-1244) */
+#define GF_BORDER_CONSTANT    0   /* cv2.BORDER_CONSTANT    */
+#define GF_BORDER_REPLICATE   1   /* cv2.BORDER_REPLICATE   ("REPLICATE") */
+#define GF_BORDER_TRANSPARENT 5   /* cv2.BORDER_TRANSPARENT ("HISTORY": dst keeps its previous pixels) */
+
+typedef void* gf_stream_t;        /* hipStream_t */
+
+GF_API int         gf_version(void);
+GF_API const char* gf_last_error(void);
+
+/* Opaque per-device context: owns the bicubic weight table in device memory. */
+GF_API int gf_ctx_create(int device, void** ctx);
+GF_API int gf_ctx_destroy(void* ctx);
+
+/* Per-frame transform consumed by the kernels: everything cv2.fisheye.initUndistortRectifyMap derives
+ * from (K, D, R, P) before its pixel loop.  iR = (P[:, :3] * R)^-1, f/c = focal/centre of K, k = D. */
+typedef struct gf_frame_xform {
+    double iR[9];
+    double f[2];
+    double c[2];
+    double k[4];
+} gf_frame_xform;
+
+/* HOST helper (no GPU work).  Builds one gf_frame_xform from the four matrices the reference hands to
+ * cv2.fisheye.initUndistortRectifyMap at calibrate_video.py:376/383 (K=scaled_K, D, R, P=new_K), all
+ * row-major host doubles.  GF_ERR_SINGULAR if P*R is not invertible. */
+GF_API int gf_make_frame_xform(const double K_host[9], const double D_host[4], const double R_host[9],
+                        const double P_host[9], gf_frame_xform* out_host);
+
+/* cv2.fisheye.initUndistortRectifyMap(K, D, R, P, (out_w,out_h), cv2.CV_16SC2)
+ *   replaces calibrate_video.py:383 (and :322 with R = I).  map1: int16 [out_h][out_w][2],
+ *   map2: uint16 [out_h][out_w] = (fy<<5)|fx, INTER_BITS = 5.  xf is a HOST pointer. */
+GF_API int gf_fisheye_maps_16sc2(void* ctx, const gf_frame_xform* xf_host, int out_w, int out_h,
+                          int16_t* map1, size_t map1_step, uint16_t* map2, size_t map2_step, gf_stream_t stream);
+
+/* cv2.fisheye.initUndistortRectifyMap(..., cv2.CV_32FC1) -- calibrate_video.py:376 (stretched presets). */
+GF_API int gf_fisheye_maps_32f(void* ctx, const gf_frame_xform* xf_host, int out_w, int out_h,
+                        float* mapx, size_t mapx_step, float* mapy, size_t mapy_step, gf_stream_t stream);
+
+/* cv2.convertMaps(mapx * sx_num / sx_den, mapy * sy_num / sy_den, cv2.CV_16SC2) -- calibrate_video.py:378.
+ * The two scalings are done in float32, multiply first then divide, each rounded, exactly as numpy
+ * evaluates `map1 * orig_w / calib_w` on a float32 array.  Pass num = den = 1 for a plain convertMaps. */
+GF_API int gf_convert_maps_32f_16sc2(void* ctx, const float* mapx, size_t mapx_step, const float* mapy, size_t mapy_step,
+                              float sx_num, float sx_den, float sy_num, float sy_den, int w, int h,
+                              int16_t* map1, size_t map1_step, uint16_t* map2, size_t map2_step, gf_stream_t stream);
+
+/* cv2.remap(src, map1, map2, cv2.INTER_LINEAR, dst, borderMode, borderValue) with CV_16SC2 + CV_16UC1 maps
+ *   replaces stabilizer.py:1442-1443 (also :1825, :2423, calibrate_video.py:325, gyroflow.py:275,283).
+ * u8: Q15 fixed-point weights, (sum + 2^14) >> 15.  u16: float32 weights, left-to-right sum, round-half-even.
+ * src and dst must not overlap.  With GF_BORDER_TRANSPARENT dst pixels whose source falls outside stay as they are.
+ * border_value_host: 4 host doubles (cv2 Scalar), only [0..2] used. */
+GF_API int gf_remap_linear_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep,
+                       void* dst, int dw, int dh, size_t dstep,
+                       const int16_t* map1, size_t map1_step, const uint16_t* map2, size_t map2_step,
+                       int border, const double border_value_host[4], gf_stream_t stream);
+
+/* cv2.remap(src_u8c3, mapx_f32, mapy_f32, cv2.INTER_CUBIC, borderMode, borderValue)
+ *   replaces nonlinear_stretch.py:130 (NonlinearStretch.apply_stretch). */
+GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep,
+                                uint8_t* dst, int dw, int dh, size_t dstep,
+                                const float* mapx, size_t mapx_step, const float* mapy, size_t mapy_step,
+                                int border, const double border_value_host[4], gf_stream_t stream);
+
+/* The fused hot path: for each of n_frames frames, get_maps() + cv2.remap(INTER_LINEAR) in one kernel; the
+ * fixed-point map is computed per output pixel in registers and never stored
+ *   replaces calibrate_video.py:383 + stabilizer.py:1442-1443 (the body of the render loop, stabilizer.py:1423-1443).
+ * Frame i reads src + i*src_frame_stride, writes dst + i*dst_frame_stride (strides in bytes; 0 is allowed for src
+ * to reuse one input) and uses xf_dev[i].  xf_dev is a DEVICE array of n_frames gf_frame_xform.
+ * Output is bit-identical to gf_fisheye_maps_16sc2 followed by gf_remap_linear_c3. */
+GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                           void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                           const gf_frame_xform* xf_dev, int n_frames,
+                           int border, const double border_value_host[4], gf_stream_t stream);
+
+/* Hyperlapse blend, replaces the numpy float64 passes at stabilizer.py:1434 (reset), :1447 (accumulate)
+ * and :1468 (truncating cast).  acc is double [n] with n = w*h*3. */
+GF_API int gf_blend_accumulate(void* ctx, int depth, const void* frame, double* acc, double weight, int reset,
+                        size_t n, gf_stream_t stream);
+GF_API int gf_blend_finalize(void* ctx, int depth, const double* acc, void* out, size_t n, gf_stream_t stream);
+
+/* Fused hot path + hyperlapse blend: output frame g = trunc( sum_{b<n_blend} (1/n_blend) * remap(frame g*group_stride+b) ),
+ * accumulated in float64 in registers in the reference's order (stabilizer.py:1431-1447,1464-1468); the
+ * intermediate remapped frames and the float64 accumulator never touch HBM.
+ * src holds n_out*... input frames: input frame index for (g,b) is g*frames_per_group + b. */
+GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                                 void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                                 const gf_frame_xform* xf_dev, int n_out, int frames_per_group, int n_blend,
+                                 int border, const double border_value_host[4], gf_stream_t stream);
+
+/* HOST: copy out the 1024x16 int16 bicubic weight table the library uses (tests compare it with the oracle's). */
+GF_API int gf_get_cubic_table(int16_t* out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GFREMAP_H */
