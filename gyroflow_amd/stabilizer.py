@@ -95,6 +95,19 @@ class NullSink:
         pass
 
 
+def frame_shard(n_frames, rank, world, multiple=1):
+    """Contiguous frame range [lo, hi) of `rank` when a clip of n_frames is split over `world` GPUs.
+
+    Frames are independent given their own (quat, fcorr, focalCenter) (stabilizer.py:1423-1443), so ranks need no
+    exchange step; shard boundaries are aligned to `multiple` (= hyperlapse_multiplier) so that no blend group
+    (stabilizer.py:1431-1468) straddles two ranks.  bg_color="HISTORY" makes frame n depend on output n-1 and does not
+    shard."""
+    units = -(-n_frames // multiple)
+    lo = (units * rank // world) * multiple
+    hi = min((units * (rank + 1) // world) * multiple, n_frames)
+    return lo, hi
+
+
 # ----------------------------------------------------------------------------- the stabilizer
 class Stabilizer:
     def __init__(self, source, calibration, stab_transform, fps, width, height, device=None):

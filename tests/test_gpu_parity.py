@@ -1,0 +1,312 @@
+"""GPU parity tests: libgfremap.so (through the C ABI, via gyroflow_amd.cv) against the CPU oracle.
+
+The oracle is the build's restatement of OpenCV 4.5.2 (parity unpinned against a real cv2 -- see
+oracle/cv_oracle.c).  Bars (BASELINE.json north_star):
+  * remap from identical fixed-point maps: bit-exact (u8 and u16, all border modes)
+  * GPU-generated maps: coordinates within 1e-3 px (float maps) / fixed-point entries identical except where the
+    exact coordinate sits within ~1e-9 px of a rounding tie (f64 atan/sqrt/inverse differ in the last ulp)
+  * fused kernel: bit-identical to GPU maps + GPU remap; <= 1 LSB against the oracle chain
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_img(rng, h, w, dtype):
+    if dtype == np.uint8:
+        return rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+    return (rng.integers(0, 1024, (h, w, 3), dtype=np.uint16) << 6).astype(np.uint16)
+
+
+def _rand_maps(rng, dh, dw, sw, sh, spread=12):
+    """Fixed-point maps covering inside, every edge/corner case and far outside."""
+    m1 = np.empty((dh, dw, 2), np.int16)
+    m1[..., 0] = rng.integers(-spread, sw + spread, (dh, dw))
+    m1[..., 1] = rng.integers(-spread, sh + spread, (dh, dw))
+    # force plenty of exact-edge coordinates
+    edge = rng.random((dh, dw)) < 0.2
+    m1[..., 0][edge] = rng.choice([-2, -1, 0, sw - 2, sw - 1, sw], size=int(edge.sum()))
+    edge = rng.random((dh, dw)) < 0.2
+    m1[..., 1][edge] = rng.choice([-2, -1, 0, sh - 2, sh - 1, sh], size=int(edge.sum()))
+    m2 = rng.integers(0, 65536, (dh, dw)).astype(np.uint16)      # high bits must be masked (& 1023)
+    m2[rng.random((dh, dw)) < 0.05] = 0
+    return m1, m2
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("border", [0, 1, 5])
+@pytest.mark.parametrize("shape", [((37, 53), (41, 67)), ((240, 320), (250, 517)), ((1, 1), (9, 130)), ((2, 3), (8, 128))])
+def test_remap_linear_bitexact(gpu, orc, dtype, border, shape):
+    from gyroflow_amd import cv
+    (sh, sw), (dh, dw) = shape
+    rng = np.random.default_rng(sh * 1000 + dw + border)
+    src = _rand_img(rng, sh, sw, dtype)
+    m1, m2 = _rand_maps(rng, dh, dw, sw, sh)
+    prev = _rand_img(rng, dh, dw, dtype)
+    bv = (7, 200, 33) if dtype == np.uint8 else (700, 65535, 12345.5)
+    want = orc.remap_linear(src, m1, m2, dst=prev.copy(), borderMode=border, borderValue=bv)
+    d = torch.from_numpy(prev.copy()).to(gpu)
+    got = cv.remap(torch.from_numpy(src).to(gpu), torch.from_numpy(m1).to(gpu), torch.from_numpy(m2).to(gpu),
+                   cv.INTER_LINEAR, dst=d, borderMode=border, borderValue=bv)
+    assert got.data_ptr() == d.data_ptr()
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_remap_linear_padded_rows_and_numpy_io(gpu, orc):
+    """Row-padded (non-contiguous rows) src/dst take the scalar-store path; numpy in -> numpy out."""
+    from gyroflow_amd import cv
+    rng = np.random.default_rng(5)
+    sh, sw, dh, dw = 60, 77, 50, 131
+    src = _rand_img(rng, sh, sw, np.uint8)
+    m1, m2 = _rand_maps(rng, dh, dw, sw, sh)
+    want = orc.remap_linear(src, m1, m2, borderMode=1)
+    big_s = torch.zeros((sh, sw + 5, 3), dtype=torch.uint8, device=gpu)
+    big_s[:, :sw] = torch.from_numpy(src).to(gpu)
+    big_d = torch.zeros((dh, dw + 3, 3), dtype=torch.uint8, device=gpu)
+    got = cv.remap(big_s[:, :sw], torch.from_numpy(m1).to(gpu), torch.from_numpy(m2).to(gpu), cv.INTER_LINEAR,
+                   dst=big_d[:, :dw], borderMode=1)
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+    assert int(big_d[:, dw:].sum()) == 0
+    got_np = cv.remap(src, m1, m2, cv.INTER_LINEAR, borderMode=1)
+    assert isinstance(got_np, np.ndarray)
+    np.testing.assert_array_equal(got_np, want)
+
+
+CASES = ["survey_capture", "c1_1080p", "c2_27k_to_1080p", "c3_4k", "c3_identity", "preview_720p", "c5_5k"]
+
+
+def _maps_close(g1, g2, o1, o2):
+    """Fixed-point maps: identical except ties -> allow < 2e-6 of entries to differ, each by exactly one Q5 step."""
+    gq = (g1.astype(np.int64) << 5) + np.stack([g2 & 31, g2 >> 5], -1)
+    oq = (o1.astype(np.int64) << 5) + np.stack([o2 & 31, o2 >> 5], -1)
+    diff = np.abs(gq - oq)
+    assert diff.max() <= 1, "a fixed-point coordinate differs by more than one 1/32 px step"
+    frac = float((diff != 0).mean())
+    assert frac < 2e-6, "too many fixed-point coordinates differ: %g" % frac
+    return frac
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_fisheye_maps_vs_oracle(gpu, orc, golden_calls, case):
+    """K2 at the sizes/params the reference's get_maps hands to cv2 (captured in tests/golden/getmaps_calls.npz)."""
+    from gyroflow_amd import cv
+    z, _ = golden_calls
+    K, D, R, P = z[case + ".K"], z[case + ".D"], z[case + ".R"], z[case + ".P"]
+    size = tuple(int(v) for v in z[case + ".size"])
+    o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, size, orc.CV_16SC2)
+    g1, g2 = cv.fisheye_initUndistortRectifyMap(K, D, R, P, size, cv.CV_16SC2, device=gpu)
+    _maps_close(g1.cpu().numpy(), g2.cpu().numpy(), o1, o2)
+    if size[0] <= 1920:
+        of1, of2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, size, orc.CV_32FC1)
+        gf1, gf2 = cv.fisheye_initUndistortRectifyMap(K, D, R, P, size, cv.CV_32FC1, device=gpu)
+        # tolerance from north_star: 1e-3 px; observed: at most one float32 ulp
+        assert np.abs(gf1.cpu().numpy().astype(np.float64) - of1).max() < 1e-3
+        assert np.abs(gf2.cpu().numpy().astype(np.float64) - of2).max() < 1e-3
+        assert (gf1.cpu().numpy() != of1).mean() < 1e-4
+
+
+def test_fisheye_maps_behind_camera(gpu, orc):
+    """Rays with _w <= 0 (rotation > 90 deg off axis) take OpenCV's +-inf branch -> map entry (0,0), fraction 0."""
+    from gyroflow_amd import cv
+    from scipy.spatial.transform import Rotation
+    K = np.array([[300., 0, 160], [0, 300., 120], [0, 0, 1]]); D = [0.05, 0.01, -0.01, 0.002]
+    R = Rotation.from_euler("y", 100, degrees=True).as_matrix()
+    o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, K, (320, 240), orc.CV_16SC2)
+    g1, g2 = cv.fisheye_initUndistortRectifyMap(K, D, R, K, (320, 240), cv.CV_16SC2, device=gpu)
+    assert (o1 == 0).all(axis=-1).any()
+    _maps_close(g1.cpu().numpy(), g2.cpu().numpy(), o1, o2)
+
+
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+@pytest.mark.parametrize("border", [0, 1, 5])
+def test_fused_equals_maps_plus_remap(gpu, orc, golden_calls, dtype, border):
+    """K1 == K4(K2) bit for bit on the GPU, and <= 1 LSB from the oracle chain (exact where the maps agree)."""
+    from gyroflow_amd import cv, _lib
+    z, _ = golden_calls
+    rng = np.random.default_rng(11)
+    case = "c2_27k_to_1080p"
+    K, D, R, P = z[case + ".K"], z[case + ".D"], z[case + ".R"], z[case + ".P"]
+    # shrink the geometry 4x so the oracle stays fast and borders are hit
+    s = 0.25
+    Ks = K.copy(); Ks[:2] *= s
+    Ps = P.copy(); Ps[:2] *= s
+    sw, sh, dw, dh = 676, 507, 480, 270
+    Rb = R.copy()
+    frames = np.stack([_rand_img(rng, sh, sw, dtype) for _ in range(3)])
+    xfs = []
+    Rs = []
+    from scipy.spatial.transform import Rotation
+    for i in range(3):
+        Ri = Rotation.from_euler("zyx", [3 * i, 2 - 4 * i, 1.5 * i], degrees=True).as_matrix() @ Rb
+        Rs.append(Ri)
+        xfs.append(_lib.xform_to_array(_lib.make_frame_xform(Ks, D, Ri, Ps)))
+    xf_dev = cv.xforms_to_device(np.stack(xfs), gpu)
+    src = torch.from_numpy(frames).to(gpu)
+    prev = np.stack([_rand_img(rng, dh, dw, dtype) for _ in range(3)])
+    dst = torch.from_numpy(prev.copy()).to(gpu)
+    bv = (10, 20, 30)
+    fused = cv.undistort_rotate(src, xf_dev, (dw, dh), dst=dst, borderMode=border, borderValue=bv).cpu().numpy()
+    for i in range(3):
+        g1, g2 = cv.fisheye_initUndistortRectifyMap(Ks, D, Rs[i], Ps, (dw, dh), cv.CV_16SC2, device=gpu)
+        two = cv.remap(src[i], g1, g2, cv.INTER_LINEAR, dst=torch.from_numpy(prev[i].copy()).to(gpu), borderMode=border,
+                       borderValue=bv).cpu().numpy()
+        np.testing.assert_array_equal(fused[i], two)
+        o1, o2 = orc.fisheye_init_undistort_rectify_map(Ks, D, Rs[i], Ps, (dw, dh), orc.CV_16SC2)
+        want = orc.remap_linear(frames[i], o1, o2, dst=prev[i].copy(), borderMode=border, borderValue=bv)
+        same_map = (g1.cpu().numpy() == o1).all(-1) & (g2.cpu().numpy() == o2)
+        np.testing.assert_array_equal(fused[i][same_map], want[same_map])
+        assert same_map.mean() > 1 - 2e-6
+
+
+def test_fused_full_size_4k_vs_oracle(gpu, orc, golden_calls):
+    """BASELINE config C3 at full size: one 3840x2160 frame, fused kernel against the oracle chain."""
+    from gyroflow_amd import cv, _lib, synthetic_frames
+    z, _ = golden_calls
+    K, D, R, P = z["c3_4k.K"], z["c3_4k.D"], z["c3_4k.R"], z["c3_4k.P"]
+    frame = synthetic_frames(3840, 2160, n=1)[0]
+    o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, (3840, 2160), orc.CV_16SC2)
+    want = orc.remap_linear(frame, o1, o2, nthreads=8)
+    xf = cv.xforms_to_device(_lib.xform_to_array(_lib.make_frame_xform(K, D, R, P))[None], gpu)
+    got = cv.undistort_rotate(torch.from_numpy(frame).to(gpu), xf, (3840, 2160)).cpu().numpy()
+    diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    nbad = int((diff != 0).sum())
+    assert nbad <= 24, "more than a handful of pixels differ from the oracle: %d" % nbad     # rounding ties only
+    # size-independent property: with an identity map (K = P, R = I, D such that scale == 1 is impossible for a
+    # fisheye) we instead check idempotence of the integer-shift case: remap by whole pixels copies pixels
+    m1 = np.zeros((2160, 3840, 2), np.int16)
+    m1[..., 0] = np.arange(3840)[None, :] + 5
+    m1[..., 1] = np.arange(2160)[:, None] - 3
+    m2 = np.zeros((2160, 3840), np.uint16)
+    sh = cv.remap(torch.from_numpy(frame).to(gpu), torch.from_numpy(m1).to(gpu), torch.from_numpy(m2).to(gpu),
+                  cv.INTER_LINEAR).cpu().numpy()
+    np.testing.assert_array_equal(sh[3:, :-5], frame[:-3, 5:])
+    assert (sh[:3] == 0).all() and (sh[:, -5:] == 0).all()
+
+
+def test_convert_maps_and_stretched_get_maps(gpu, orc, golden_calls):
+    """K3 + the stretched-preset branch of get_maps (calibrate_video.py:375-380)."""
+    from gyroflow_amd import cv, FisheyeCalibrator
+    from conftest import preset_path
+    rng = np.random.default_rng(3)
+    mx = (rng.random((61, 97)) * 5000 - 1000).astype(np.float32)
+    my = (rng.random((61, 97)) * 80000 - 40000).astype(np.float32)      # exercises saturate_cast<short>
+    mx[0, :4] = [0.015625, 0.046875, -0.015625, 1e9]                      # ties at .5/32 and overflow
+    o1, o2 = orc.convert_maps(mx, my)
+    g1, g2 = cv.convertMaps(torch.from_numpy(mx).to(gpu), torch.from_numpy(my).to(gpu))
+    np.testing.assert_array_equal(g1.cpu().numpy(), o1)
+    np.testing.assert_array_equal(g2.cpu().numpy(), o2)
+    # numpy float32 scaling as the reference does it
+    sx = (mx * 3840 / 2880).astype(np.float32)
+    sy = (my * 2160 / 2160).astype(np.float32)
+    assert sx.dtype == np.float32
+    o1, o2 = orc.convert_maps(mx * 3840 / 2880, my * 2160 / 2160)
+    g1, g2 = cv.convertMaps(torch.from_numpy(mx).to(gpu), torch.from_numpy(my).to(gpu), scale_x=(3840, 2880), scale_y=(2160, 2160))
+    np.testing.assert_array_equal(g1.cpu().numpy(), o1)
+    np.testing.assert_array_equal(g2.cpu().numpy(), o2)
+
+    z, meta = golden_calls
+    kw = [m for m in meta if m["name"] == "stretched_runcam"][0]["kwargs"]
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("runcam5_stretched"))
+    g1, g2 = cal.get_maps(fov_scale=kw["fov_scale"], new_img_dim=tuple(kw["new_img_dim"]), output_dim=tuple(kw["output_dim"]),
+                          update_new_K=False, quat=np.array(kw["quat"]), focalCenter=None, device=gpu)
+    c = "stretched_runcam"
+    f1, f2 = orc.fisheye_init_undistort_rectify_map(z[c + ".K"], z[c + ".D"], z[c + ".R"], z[c + ".P"],
+                                                    tuple(int(v) for v in z[c + ".size"]), orc.CV_32FC1)
+    o1, o2 = orc.convert_maps(f1 * cal.orig_dimension[0] / cal.calib_dimension[0],
+                              f2 * cal.orig_dimension[1] / cal.calib_dimension[1])
+    gq = (g1.cpu().numpy().astype(np.int64) << 5) + np.stack([g2.cpu().numpy() & 31, g2.cpu().numpy() >> 5], -1)
+    oq = (o1.astype(np.int64) << 5) + np.stack([o2 & 31, o2 >> 5], -1)
+    assert np.abs(gq - oq).max() <= 1 and (gq != oq).mean() < 1e-4     # float32 maps differ by <= 1 ulp at ties
+
+
+@pytest.mark.parametrize("border", [0, 1, 5])
+def test_remap_cubic_bitexact(gpu, orc, border):
+    from gyroflow_amd import cv
+    rng = np.random.default_rng(21 + border)
+    sh, sw, dh, dw = 45, 61, 57, 83
+    src = _rand_img(rng, sh, sw, np.uint8)
+    mx = (rng.random((dh, dw)) * (sw + 12) - 6).astype(np.float32)
+    my = (rng.random((dh, dw)) * (sh + 12) - 6).astype(np.float32)
+    mx[0, :6] = [-1.0, 0.0, 1.0, sw - 3, sw - 2, sw - 1]
+    my[0, :6] = [1.0, 0.0, -1.0, sh - 3, sh - 2, sh - 1]
+    prev = _rand_img(rng, dh, dw, np.uint8)
+    want = orc.remap_cubic(src, mx, my, dst=prev.copy(), borderMode=border, borderValue=(9, 99, 199))
+    got = cv.remap(torch.from_numpy(src).to(gpu), torch.from_numpy(mx).to(gpu), torch.from_numpy(my).to(gpu), cv.INTER_CUBIC,
+                   dst=torch.from_numpy(prev.copy()).to(gpu), borderMode=border, borderValue=(9, 99, 199))
+    np.testing.assert_array_equal(got.cpu().numpy(), want)
+
+
+def test_nonlinear_stretch_apply(gpu, orc):
+    """NonlinearStretch.apply_stretch (nonlinear_stretch.py:120-139) == oracle bicubic remap of the same maps."""
+    from gyroflow_amd import NonlinearStretch, synthetic_frames
+    ns = NonlinearStretch((400, 300), (384, 216))
+    ns.recompute_maps()
+    img = synthetic_frames(400, 300, n=1)[0]
+    want = orc.remap_cubic(img, ns.map1, ns.map2)
+    got = ns.apply_stretch(img)
+    assert isinstance(got, np.ndarray) and got.shape == (216, 384, 3)
+    np.testing.assert_array_equal(got, want)
+    got_t = ns.apply_stretch(torch.from_numpy(img).to(gpu))
+    np.testing.assert_array_equal(got_t.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("dtype,tdtype", [(np.uint8, torch.uint8), (np.uint16, torch.uint16)])
+@pytest.mark.parametrize("n", [2, 3, 4])
+def test_blend_passes_and_fused_blend(gpu, orc, dtype, tdtype, n):
+    """K6 unfused passes and the fused remap+blend kernel against numpy's float64 order (stabilizer.py:1434-1468)."""
+    from gyroflow_amd import cv, _lib
+    rng = np.random.default_rng(n)
+    sh, sw, dh, dw = 90, 120, 80, 132
+    K = np.array([[80., 0, 60], [0, 80., 45], [0, 0, 1]]); D = [0.03, -0.01, 0.004, 0.0]
+    P = np.array([[75., 0, 66], [0, 75., 40], [0, 0, 1]])
+    from scipy.spatial.transform import Rotation
+    frames = np.stack([_rand_img(rng, sh, sw, dtype) for _ in range(2 * n + 1)])
+    Rs = [Rotation.from_euler("zyx", [i, -i * 0.7, 0.5 * i], degrees=True).as_matrix() for i in range(2 * n + 1)]
+    xf = np.stack([_lib.xform_to_array(_lib.make_frame_xform(K, D, R, P)) for R in Rs])
+    src = torch.from_numpy(frames).to(gpu)
+    xf_dev = cv.xforms_to_device(xf, gpu)
+    remapped = cv.undistort_rotate(src, xf_dev, (dw, dh), borderMode=1)
+    # numpy reference order on the GPU-remapped frames
+    want = []
+    for g in range(2):
+        acc = np.zeros((dh, dw, 3), np.float64) * 0.0
+        for b in range(n):
+            acc += 1 / n * remapped[g * n + b].cpu().numpy().astype(np.float64)
+        want.append(acc.astype(dtype))
+    fused = cv.undistort_rotate_blend(src, xf_dev, (dw, dh), n, n, borderMode=1).cpu().numpy()
+    assert fused.shape[0] == 2
+    np.testing.assert_array_equal(fused, np.stack(want))
+    acc = torch.full((dh, dw, 3), 5.0, dtype=torch.float64, device=gpu)
+    for b in range(n):
+        cv.blend_accumulate(remapped[b], acc, 1 / n, reset=(b == 0))
+    np.testing.assert_array_equal(cv.blend_finalize(acc, tdtype).cpu().numpy(), want[0])
+    # oracle's own blend restatement agrees with numpy's
+    oacc = np.full((dh, dw, 3), 5.0)
+    for b in range(n):
+        orc.blend_accumulate(remapped[b].cpu().numpy(), oacc, 1 / n, b == 0)
+    np.testing.assert_array_equal(orc.blend_finalize(oacc, dtype), want[0])
+
+
+def test_error_codes(gpu):
+    """The C ABI rejects bad arguments with a code + message and never launches."""
+    import ctypes as C
+    from gyroflow_amd import _lib, cv
+    lib, ctx = _lib.load(), _lib.ctx(0)
+    s = torch.zeros((8, 8, 3), dtype=torch.uint8, device=gpu)
+    m1 = torch.zeros((8, 8, 2), dtype=torch.int16, device=gpu); m2 = torch.zeros((8, 8), dtype=torch.uint16, device=gpu)
+    bv = _lib.border_value(0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.gf_remap_linear_c3(ctx, 1, p(s), 8, 8, 24, p(s), 8, 8, 24, p(m1), 32, p(m2), 16, 0, bv, None) == -3
+    assert lib.gf_remap_linear_c3(ctx, 0, p(s), 8, 8, 24, p(s), 8, 8, 24, p(m1), 32, p(m2), 16, 0, bv, None) == -1   # overlap
+    assert b"overlap" in lib.gf_last_error()
+    d = torch.zeros((8, 8, 3), dtype=torch.uint8, device=gpu)
+    assert lib.gf_remap_linear_c3(ctx, 0, p(s), 8, 8, 23, p(d), 8, 8, 24, p(m1), 32, p(m2), 16, 0, bv, None) == -1   # step < row
+    assert lib.gf_remap_linear_c3(ctx, 0, p(s), 8, 8, 24, p(d), 8, 8, 24, p(m1), 32, p(m2), 16, 3, bv, None) == -3   # border mode
+    assert lib.gf_remap_linear_c3(ctx, 0, p(s), 40000, 8, 120000, p(d), 8, 8, 24, p(m1), 32, p(m2), 16, 0, bv, None) == -1
+    with pytest.raises(_lib.GfError):
+        _lib.make_frame_xform(np.eye(3), np.zeros(4), np.zeros((3, 3)), np.eye(3))
+    with pytest.raises(TypeError):
+        cv.remap(torch.zeros((4, 4, 3), dtype=torch.float32, device=gpu), m1[:4, :4], m2[:4, :4], cv.INTER_LINEAR)

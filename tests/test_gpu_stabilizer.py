@@ -1,0 +1,116 @@
+"""Render-loop parity: gyroflow_amd.Stabilizer.renderfile against the reference loop's order of operations
+(/root/reference/stabilizer.py:1378-1522) restated below on top of the CPU oracle.  Small frames, every mode."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import preset_path
+
+pytestmark = pytest.mark.gpu
+
+
+def reference_loop(orc, cal, frames, fail_at, stab, fps, start, stop, out_size, fov_scale, bg_color, mult, nblend,
+                   orig_dim):
+    """The body of Stabilizer.renderfile (reference), with cv2 replaced by the oracle and fcorr == 1
+    (smoothingFocus = -2, adaptive_zoom.py:152-153).  Returns the list of written frames."""
+    from gyroflow_amd import Stabilizer
+    borderMode, borderValue = Stabilizer.border_from_bg_color(bg_color)
+    num_frames = int((stop - start) * fps)
+    pos = int(start * fps)
+    out = []
+    frame_out = None
+    frame_temp = np.zeros((out_size[1], out_size[0], 3), np.float64)
+    nblend = min(mult, nblend)
+    num_not_success = 0
+    for i in range(1, num_frames):
+        frame_num = pos
+        success = pos < len(frames) and pos not in fail_at
+        frame = frames[pos] if success else None
+        if pos < len(frames):
+            pos += 1
+        if success:
+            num_not_success = 0
+        elif num_not_success >= 5:
+            break
+        else:
+            num_not_success += 1
+        if frame_num >= len(stab):
+            break
+        if not success:
+            continue
+        K, D, R, P, od = cal._frame_matrices(fov_scale * 1.0, out_size, orig_dim, stab[frame_num],
+                                             np.array([cal.calib_dimension[0] / 2, cal.calib_dimension[1] / 2]), True)
+        m1, m2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, od, orc.CV_16SC2)
+        if (i - 1) % mult == 0 and nblend > 1:
+            frame_temp = frame_temp * 0.0
+        if (i - 1) % mult < nblend:
+            frame_out = orc.remap_linear(frame, m1, m2, dst=frame_out, borderMode=borderMode, borderValue=borderValue)
+            if nblend > 1:
+                frame_temp += 1 / nblend * frame_out.astype(np.float64)
+        if ((i - 1) - nblend + 1) % mult == 0:
+            if nblend > 1:
+                frame_out = frame_temp.astype(frame.dtype)
+            out.append(frame_out.copy())
+    return out
+
+
+def _quats(n, seed=0):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(seed)
+    e = np.cumsum(rng.normal(0, 0.8, (n, 3)), axis=0)
+    q = Rotation.from_euler("zyx", e, degrees=True).as_quat()
+    return q[:, [3, 0, 1, 2]]
+
+
+@pytest.mark.parametrize("mode", [
+    dict(bg="#000000", mult=1, nblend=1),
+    dict(bg="#336699", mult=1, nblend=1, batch=5),
+    dict(bg="REPLICATE", mult=3, nblend=1),
+    dict(bg="REPLICATE", mult=4, nblend=2, batch=6),
+    dict(bg="#102030", mult=4, nblend=4, dtype=np.uint16),
+    dict(bg="HISTORY", mult=1, nblend=1),
+    dict(bg="HISTORY", mult=3, nblend=2),
+    dict(bg="#000000", mult=1, nblend=1, fail_at=(4, 9, 10)),
+    dict(bg="#000000", mult=2, nblend=2, sequential=True, fail_at=(5,)),
+    dict(bg="#000000", mult=1, nblend=1, short_stab=True),
+])
+def test_renderfile_matches_reference_loop(gpu, orc, mode):
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, synthetic_frames
+    dtype = mode.get("dtype", np.uint8)
+    w, h = 338, 254                         # 2704x2028 / 8
+    n = 30
+    frames = synthetic_frames(w, h, n=n, dtype=dtype, seed=7)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    stab = _quats(21 if mode.get("short_stab") else n + 5, seed=3)
+    fail_at = mode.get("fail_at", ())
+    fps, start, stop = 10.0, 0.2, 2.9
+    out_size = (240, 136)
+    st = Stabilizer(ArraySource(frames, fail_at=fail_at), cal, stab, fps, w, h, device=gpu)
+    st.set_hyperlapse(mode["mult"], mode["nblend"])
+    sink = ListSink()
+    nw = st.renderfile(start, stop, sink, out_size=out_size, fov_scale=1.3, bg_color=mode["bg"],
+                       batch=mode.get("batch", 8), sequential=mode.get("sequential", False))
+    want = reference_loop(orc, cal, frames, set(fail_at), stab, fps, start, stop, out_size, 1.3, mode["bg"], mode["mult"],
+                          mode["nblend"], (w, h))
+    assert nw == len(sink.frames) == len(want) and nw > 0
+    for a, b in zip(sink.frames, want):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_map_function_preview(gpu, orc):
+    """map_function (stabilizer.py:1205-1215) + remap, the preview path of gyroflow.py:281-283."""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, synthetic_frames, cv
+    w, h = 480, 270
+    frames = synthetic_frames(w, h, n=2)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero7_4k_169"))
+    stab = _quats(4, seed=1)
+    st = Stabilizer(ArraySource(frames), cal, stab, 30.0, w, h, device=gpu)
+    m1, m2 = st.map_function(9, out_size=(320, 180))           # clamps to the last frame
+    K, D, R, P, od = cal._frame_matrices(0.9, (320, 180), (w, h), stab[3], None, True)
+    o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, od, orc.CV_16SC2)
+    np.testing.assert_array_equal(m1.cpu().numpy(), o1)
+    np.testing.assert_array_equal(m2.cpu().numpy(), o2)
+    got = cv.remap(frames[1], m1, m2, cv.INTER_LINEAR)
+    np.testing.assert_array_equal(got, orc.remap_linear(frames[1], o1, o2))
