@@ -82,14 +82,9 @@ def main():
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
+    from gyroflow_amd import dist as gdist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)      # timing barrier only; no data-path collective
+    rank, local_rank, world = gdist.init_from_env()      # gloo: timing barrier only; no data-path collective
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
 
@@ -129,8 +124,7 @@ def main():
     torch.cuda.synchronize(dev)
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(K)]
-    if world > 1:
-        dist.barrier()
+    gdist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for s in range(K):
@@ -139,18 +133,10 @@ def main():
         ev1[s].record()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        dist.barrier()
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    gdist.barrier()
+    elapsed = gdist.max_over_ranks(elapsed)
+    kernel_ms = gdist.max_over_ranks(float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)])))
     checksum = int(dst[0, ::64, ::64].to(torch.int64).sum())
-
-    if world > 1:
-        km = torch.tensor([kernel_ms], dtype=torch.float64)
-        dist.all_reduce(km, op=dist.ReduceOp.MAX)
-        kernel_ms = float(km[0])
 
     if rank == 0:
         bytes_per_launch = algorithmic_bytes_per_frame(args.config) * B
@@ -186,8 +172,7 @@ def main():
                 threads = min(16, os.cpu_count() or 1)
                 out["cpu_baseline"] = cpu_baseline(args.config, cal, quats, ring, n_cpu, threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    gdist.shutdown()
 
 
 if __name__ == "__main__":

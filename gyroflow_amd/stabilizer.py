@@ -127,7 +127,10 @@ class Stabilizer:
         self.hyperlapse_multiplier = 1
         self.hyperlapse_num_blended_frames = 1
         self.hyperlapse_skipped_frames = 0
-        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        if device is not None:
+            self.device = torch.device(device)
+        else:       # no GPU: only the host-side logic (schedule(), border selection) is usable
+            self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         self.adaptive_zoom = None          # optional callable: (stab_transform, out_size, fps, smoothingFocus, tstart, tend) -> (fcorr, focalCenter)
 
     def set_hyperlapse(self, hyperlapse_multiplier=1, hyperlapse_num_blended_frames=1):
@@ -172,23 +175,55 @@ class Stabilizer:
                                           quat=self.stab_transform[frame_num], focalCenter=focal)
 
     # ------------------------------------------------------------------ render loop
+    def schedule(self, first_pos, n_iter, first_iter=0):
+        """The reference loop's control flow (stabilizer.py:1378-1411, 1431-1438, 1464) without any pixel work.
+
+        Reads n_iter frames starting at source position first_pos and yields, for every successfully read frame,
+        (frame_num, frame, phase, remap, emit): phase = (i-1) % hyperlapse_multiplier with i the reference's loop
+        counter, remap = the frame is inside the blended window, emit = an output frame is written after it.
+        Stops on exhausted stab_transform or after more than five consecutive failed reads.  Pure host logic."""
+        mult, nblend = self.hyperlapse_multiplier, self.hyperlapse_num_blended_frames
+        self.cap.set_pos(first_pos)
+        num_not_success, num_not_success_lim = 0, 5
+        for k in range(first_iter, first_iter + n_iter):          # k = i - 1
+            frame_num = int(self.cap.get_pos())
+            success, frame = self.cap.read()
+            if success:
+                num_not_success = 0
+            elif num_not_success >= num_not_success_lim:
+                print("Unable to read multiple frames")
+                return
+            else:
+                num_not_success += 1
+            if frame_num >= len(self.stab_transform):
+                print("No more stabilization data. Stopping render here.")
+                return
+            if not success:
+                continue
+            phase = k % mult
+            yield frame_num, frame, phase, phase < nblend, (phase - nblend + 1) % mult == 0
+
     def renderfile(self, starttime, stoptime, sink, out_size=(1920, 1080), fov_scale=1.0, smoothingFocus=-2,
-                   bg_color="#000000", batch=8, pipeline_depth=2, sequential=False):
+                   bg_color="#000000", batch=8, pipeline_depth=2, sequential=False, rank=0, world=1):
         """Render [starttime, stoptime) through the fused undistort+rotate kernel into `sink`.
 
-        Returns the number of frames written.  `sequential=True` (always used for bg_color="HISTORY", stretched
-        presets and after a failed read) issues the reference's per-frame sequence get_maps -> remap -> blend;
-        otherwise frames are batched through the pinned three-stream pipeline and the fused kernels."""
+        Returns the number of frames written.  `sequential=True` (always used for bg_color="HISTORY" and stretched
+        presets) issues the reference's per-frame sequence get_maps -> remap -> blend; otherwise frames are batched
+        through the pinned three-stream pipeline and the fused kernels.  With world > 1 this rank renders only its
+        contiguous shard of the loop iterations (frame_shard); concatenating the ranks' outputs in rank order gives
+        the single-GPU result."""
         borderMode, borderValue = self.border_from_bg_color(bg_color)
         num_frames = int((stoptime - starttime) * self.fps)
         tstart = int(starttime * self.fps)
         tend = tstart + num_frames
         fcorr, focalCenter = self._fov_terms(out_size, smoothingFocus, tstart, tend)
 
-        self.cap.set_pos(int(starttime * self.fps))
         mult, nblend = self.hyperlapse_multiplier, self.hyperlapse_num_blended_frames
         if borderMode == cv.BORDER_TRANSPARENT or self.undistort.image_is_stretched():
             sequential = True
+        if world > 1 and borderMode == cv.BORDER_TRANSPARENT:
+            raise ValueError('bg_color="HISTORY" makes every frame depend on the previous output: it does not shard')
+        lo, hi = frame_shard(max(num_frames - 1, 0), rank, world, mult)     # the loop runs i = 1 .. num_frames-1
 
         written = [0]
 
@@ -221,27 +256,8 @@ class Stabilizer:
                 return n_groups
             pipe.submit(frames, launch)
 
-        num_not_success, num_not_success_lim = 0, 5
-        for i in range(1, num_frames):
-            frame_num = int(self.cap.get_pos())
-            success, frame = self.cap.read()
-            if success:
-                num_not_success = 0
-            elif num_not_success >= num_not_success_lim:
-                print("Unable to read multiple frames")
-                break
-            else:
-                num_not_success += 1
-            if frame_num >= len(self.stab_transform):
-                print("No more stabilization data. Stopping render here.")
-                break
-            if not success:
-                if not sequential and nblend > 1:
-                    # a hole inside a blend group: finish this clip in the reference's per-frame order
-                    raise NotImplementedError("failed read inside a hyperlapse blend group: render with sequential=True")
-                continue
-
-            phase = (i - 1) % mult
+        group_phases = []                       # phases seen in the current blend group (batched path)
+        for frame_num, frame, phase, do_remap, do_emit in self.schedule(tstart + lo, hi - lo, first_iter=lo):
             if dtype is None:
                 dtype = torch.uint8 if frame.dtype == np.uint8 else torch.uint16
             fov = fov_scale * fcorr[frame_num]
@@ -250,7 +266,7 @@ class Stabilizer:
                 if seq is None:
                     seq = dict(frame_out=None, frame_temp=torch.zeros((out_size[1], out_size[0], 3), dtype=torch.float64, device=self.device))
                 reset = phase == 0 and nblend > 1          # frame_temp * 0.0 at the start of a hyperlapse group
-                if phase < nblend:
+                if do_remap:
                     m1, m2 = self.undistort.get_maps(fov, new_img_dim=self.orig_dimension, output_dim=out_size,
                                                      update_new_K=False, quat=self.stab_transform[frame_num],
                                                      focalCenter=focalCenter[frame_num], device=self.device)
@@ -259,13 +275,20 @@ class Stabilizer:
                                                 borderValue=borderValue)
                     if nblend > 1:
                         cv.blend_accumulate(seq["frame_out"], seq["frame_temp"], 1 / nblend, reset)
-                if (phase - nblend + 1) % mult == 0 and seq["frame_out"] is not None:
+                if do_emit and seq["frame_out"] is not None:
                     if nblend > 1:
                         seq["frame_out"] = cv.blend_finalize(seq["frame_temp"], dtype)
                     emit([seq["frame_out"].cpu().numpy()])
                 continue
 
-            if phase < nblend:
+            if do_remap:
+                if nblend > 1:
+                    # the fused blend kernel needs whole groups: phases 0..nblend-1 in order, no failed read between
+                    if phase == 0:
+                        group_phases = []
+                    group_phases.append(phase)
+                    if group_phases != list(range(len(group_phases))):
+                        raise NotImplementedError("failed read inside a hyperlapse blend group: render with sequential=True")
                 if pipe is None:
                     out_batch = batch if nblend == 1 else max(1, batch // nblend)
                     in_batch = out_batch * nblend

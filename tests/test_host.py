@@ -1,0 +1,192 @@
+"""CPU tests of the host-side mirror against data captured from the reference's own Python
+(tests/golden/*.npz, written by tests/golden/make_golden.py) and of the C ABI's surface."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, preset_path
+
+
+def _cal(key):
+    from gyroflow_amd import FisheyeCalibrator
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path(key))
+    return cal
+
+
+def test_frame_matrices_equal_reference_capture(golden_calls):
+    """What our get_maps hands to the kernels == what the reference's get_maps hands to cv2 (bit for bit):
+    scaled_K, D, R (quat -> matrix + axis flips), new_K, output size, map type."""
+    z, meta = golden_calls
+    assert len(meta) >= 9
+    for m in meta:
+        cal = _cal(m["preset"])
+        kw = dict(m["kwargs"])
+        quat = kw.get("quat")
+        fc = kw.get("focalCenter")
+        K, D, R, P, od = cal._frame_matrices(kw.get("fov_scale", 1.0),
+                                             tuple(kw["output_dim"]) if kw.get("output_dim") else None,
+                                             tuple(kw["new_img_dim"]) if kw.get("new_img_dim") else None,
+                                             None if quat is None else np.array(quat),
+                                             None if fc is None else np.array(fc),
+                                             kw.get("original_stretched", True))
+        n = m["name"]
+        np.testing.assert_array_equal(K, z[n + ".K"])
+        np.testing.assert_array_equal(np.asarray(D, np.float64).reshape(-1), z[n + ".D"])
+        np.testing.assert_array_equal(R, z[n + ".R"])
+        np.testing.assert_array_equal(P, z[n + ".P"])
+        assert tuple(od) == tuple(int(v) for v in z[n + ".size"])
+        stretched = cal.image_is_stretched()
+        assert int(z[n + ".m1type"]) == (5 if stretched else 11)
+        assert m["converted"] == stretched and (not stretched or m["convert_in_dtype"] == "float32")
+
+
+def test_survey_known_values(golden_calls):
+    """The values quoted in SURVEY.md 8(c) for the Hero8 capture."""
+    cal = _cal("hero8_27k_43")
+    q = np.array([0.9990482215818578, 0.02, -0.03, 0.025]); q /= np.linalg.norm(q)
+    K, D, R, P, od = cal._frame_matrices(0.8, (1920, 1080), (2704, 2028), q, np.array([1352., 1014.]), True)
+    assert P.tolist() == [[1490.6551163044169, 0.0, 960.0], [0.0, 1493.7196642070426, 540.0], [0.0, 0.0, 1.0]]
+    assert R[0].tolist() == [0.9969500681630664, 0.0511512678970602, 0.058941576006925456]
+    np.testing.assert_array_equal(K, cal.K)          # ratio 1 -> scaled_K == K with [2][2] = 1
+
+
+def test_update_new_K_side_effect_and_reentrancy():
+    cal = _cal("hero7_4k_169")
+    K0 = cal.K.copy()
+    a = cal._frame_matrices(1.3, (1280, 720), (3840, 2160), np.array([1, 0, 0, 0.]), None, True)
+    b = cal._frame_matrices(1.3, (1280, 720), (3840, 2160), np.array([1, 0, 0, 0.]), None, True)
+    np.testing.assert_array_equal(cal.K, K0)         # read-only use of K/D: safe from the preview thread
+    np.testing.assert_array_equal(a[3], b[3])
+    np.testing.assert_array_equal(a[2], np.eye(3))
+
+
+def test_preset_loader_errors(tmp_path):
+    from gyroflow_amd import FisheyeCalibrator
+    with open(preset_path("hero8_27k_43")) as f:
+        d = json.load(f)
+    cal = FisheyeCalibrator()
+    info = cal.load_calibration_data(d)
+    assert info["width"] == 2704 and info["height"] == 2028 and cal.input_horizontal_stretch == 1
+    assert tuple(cal.calib_dimension) == (2704, 2028) and cal.K.shape == (3, 3) and len(cal.D) == 4
+    bad = dict(d); bad["use_opencv_fisheye"] = False
+    with pytest.raises(Exception, match="Preset not for OpenCV fisheye lens model"):
+        FisheyeCalibrator().load_calibration_data(bad)
+    bad = dict(d); del bad["fisheye_params"]
+    with pytest.raises(KeyError):
+        FisheyeCalibrator().load_calibration_data(bad)
+    cal = _cal("runcam5_stretched")
+    assert cal.image_is_stretched() and cal.input_horizontal_stretch == 0.75
+    assert cal.get_stretched_size_from_dimension((3840, 2160)) == (2880, 2160)
+
+
+def test_nonlinear_stretch_maps_equal_reference():
+    """recompute_maps() == the reference's numpy arithmetic, every float32 bit (captured in stretch_maps.npz)."""
+    from gyroflow_amd import NonlinearStretch
+    z = np.load(os.path.join(GOLDEN, "stretch_maps.npz"))
+    for tag in ("s0", "s1", "s2", "s3", "s4"):
+        p = z[tag + ".params"]
+        ns = NonlinearStretch((int(p[0]), int(p[1])), (int(p[2]), int(p[3])))
+        ns.set_safe_area(p[4]); ns.set_expo(p[5] if p[5] != int(p[5]) else int(p[5]))
+        ns.recompute_maps()
+        assert ns.map1.dtype == np.float32 and ns.map1.shape == (int(p[3]), int(p[2]))
+        np.testing.assert_array_equal(ns.map1, z[tag + ".map1"])
+        np.testing.assert_array_equal(ns.map2, z[tag + ".map2"])
+    ns = NonlinearStretch((4000, 3000), (3840, 2160))
+    ns.recompute_maps()
+    np.testing.assert_array_equal(ns.map1[z["c4.rows"], :], z["c4.map1_rows"])
+    np.testing.assert_array_equal(ns.map2[:, z["c4.cols"]], z["c4.map2_cols"])
+    # the values quoted in SURVEY.md 8(c)
+    np.testing.assert_allclose(ns.map1[0, [0, 1, 1919, 1920, 3839]], [-0.5, 0.19462529, 1998.1113, 1999.5, 3998.8054], rtol=1e-7)
+    np.testing.assert_allclose(ns.map2[[0, 1, 2159], 0], [-0.5, 0.8888889, 2998.111], rtol=1e-7)
+    ns = NonlinearStretch()
+    ns.set_safe_area(5)
+    assert ns.safe_area == 0.999
+
+
+def test_border_from_bg_color_and_hyperlapse():
+    from gyroflow_amd import Stabilizer, cv
+    assert Stabilizer.border_from_bg_color("REPLICATE") == (cv.BORDER_REPLICATE, 0)
+    assert Stabilizer.border_from_bg_color("HISTORY") == (cv.BORDER_TRANSPARENT, 0)
+    assert Stabilizer.border_from_bg_color("#000000") == (cv.BORDER_CONSTANT, [0, 0, 0])
+    assert Stabilizer.border_from_bg_color("#336699") == (cv.BORDER_CONSTANT, [153, 102, 51])     # RGB -> BGR
+    assert Stabilizer.border_from_bg_color("red") == (cv.BORDER_CONSTANT, [0, 0, 255])
+
+
+def test_frame_shard_partitions():
+    from gyroflow_amd.stabilizer import frame_shard
+    for n, world, mult in [(3600, 1, 1), (3600, 8, 1), (3600, 7, 4), (10, 4, 4), (5, 8, 1), (1201, 3, 4)]:
+        cover = []
+        for r in range(world):
+            lo, hi = frame_shard(n, r, world, mult)
+            assert lo % mult == 0 and lo <= hi <= n
+            cover += list(range(lo, hi))
+        assert cover == list(range(n))
+
+
+def test_abi_exports_every_declared_symbol():
+    """libgfremap.so loads without a GPU and exports exactly what include/gfremap.h declares."""
+    with open(os.path.join(ROOT, "include", "gfremap.h")) as f:
+        hdr = f.read()
+    declared = set(re.findall(r"GF_API\s+(?:const\s+char\*|int)\s+(gf_\w+)\s*\(", hdr))
+    assert len(declared) >= 15
+    from gyroflow_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert declared == set(_lib.SIGNATURES), "ctypes prototypes out of sync with the header"
+    assert _lib.load().gf_version() == int(re.search(r"#define GF_VERSION (\d+)", hdr).group(1))
+    assert ctypes.sizeof(_lib.FrameXform) == 17 * 8
+
+
+def test_host_only_abi_calls(orc):
+    """gf_make_frame_xform / gf_get_cubic_table do no GPU work: checked here against the oracle."""
+    from gyroflow_amd import _lib, cv
+    z = np.load(os.path.join(GOLDEN, "getmaps_calls.npz"))
+    xf = _lib.make_frame_xform(z["c2_27k_to_1080p.K"], z["c2_27k_to_1080p.D"], z["c2_27k_to_1080p.R"], z["c2_27k_to_1080p.P"])
+    a = _lib.xform_to_array(xf)
+    np.testing.assert_array_equal(a[:9].reshape(3, 3), orc.compute_iR(z["c2_27k_to_1080p.R"], z["c2_27k_to_1080p.P"]))
+    K = z["c2_27k_to_1080p.K"]
+    assert a[9:13].tolist() == [K[0, 0], K[1, 1], K[0, 2], K[1, 2]]
+    np.testing.assert_array_equal(a[13:], z["c2_27k_to_1080p.D"])
+    with pytest.raises(_lib.GfError) as e:
+        _lib.make_frame_xform(np.eye(3), np.zeros(4), np.zeros((3, 3)), np.eye(3))
+    assert e.value.code == -4 and "singular" in str(e.value)
+    np.testing.assert_array_equal(cv.cubic_table(), orc.cubic_tab()[1])
+
+
+def test_product_does_not_import_oracle():
+    """The product path must never route through the oracle."""
+    pkg = os.path.join(ROOT, "gyroflow_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            with open(os.path.join(pkg, fn)) as f:
+                src = f.read()
+            assert "oracle" not in src.replace("oracle's", ""), fn
+    with open(os.path.join(pkg, "csrc", "gfremap.hip")) as f:
+        assert "cv_oracle" not in f.read()
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from gyroflow_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libgfremap.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_golden_quaternion_fixtures():
+    """The reference-generated quaternion traces the benchmarks use."""
+    q = np.load(os.path.join(GOLDEN, "quats_rollpitchyaw.npz"))["stab_transform"]
+    assert q.shape == (300, 4)
+    np.testing.assert_allclose(q[0], [0.999999999997, -1.023058603972e-10, -5.589539942008e-11, -2.454242589352e-06], atol=1e-12)
+    np.testing.assert_allclose(q[150], [0.9988806643244, 0.04730000819578, -3.572948769755e-04, 1.974852067112e-06], atol=1e-12)
+    g = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
+    st = g["stab_transform"]
+    assert st.shape == (1622, 7) and float(g["min_fcorr"]) == 2.1857348445009372
+    ang = 2 * np.degrees(np.arccos(np.clip(np.abs(st[:, 3] / np.linalg.norm(st[:, 3:7], axis=1)), 0, 1)))
+    assert 3.0 < ang.mean() < 4.2 and 12.5 < ang.max() < 14.0          # mean 3.6 deg, max 13.4 deg
