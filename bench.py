@@ -117,7 +117,7 @@ def main():
     border = cv.BORDER_CONSTANT if args.border == "constant" else cv.BORDER_REPLICATE
 
     def step(s):
-        cv.undistort_rotate(src, xf_dev[s], (ow, oh), dst=dst, borderMode=border)
+        cv.undistort_rotate(src, cal.D, xf_dev[s], (ow, oh), dst=dst, borderMode=border)
 
     for s in range(W):
         step(s)

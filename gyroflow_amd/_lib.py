@@ -22,11 +22,11 @@ class GfError(RuntimeError):
 
 
 class FrameXform(C.Structure):
-    """gf_frame_xform: iR[9], f[2], c[2], k[4] (17 doubles)."""
-    _fields_ = [("iR", C.c_double * 9), ("f", C.c_double * 2), ("c", C.c_double * 2), ("k", C.c_double * 4)]
+    """gf_frame_xform: iR[9], f[2], c[2] (13 doubles)."""
+    _fields_ = [("iR", C.c_double * 9), ("f", C.c_double * 2), ("c", C.c_double * 2)]
 
 
-XFORM_DOUBLES = 17
+XFORM_DOUBLES = 13
 assert C.sizeof(FrameXform) == XFORM_DOUBLES * 8
 
 _vp, _sz, _i, _d, _f = C.c_void_p, C.c_size_t, C.c_int, C.c_double, C.c_float
@@ -38,17 +38,18 @@ SIGNATURES = {
     "gf_last_error": [],
     "gf_ctx_create": [_i, C.POINTER(_vp)],
     "gf_ctx_destroy": [_vp],
-    "gf_make_frame_xform": [_dp, _dp, _dp, _dp, C.POINTER(FrameXform)],
-    "gf_fisheye_maps_16sc2": [_vp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
-    "gf_fisheye_maps_32f": [_vp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
+    "gf_make_frame_xform": [_dp, _dp, _dp, C.POINTER(FrameXform)],
+    "gf_fisheye_maps_16sc2": [_vp, _dp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
+    "gf_fisheye_maps_32f": [_vp, _dp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
     "gf_convert_maps_32f_16sc2": [_vp, _vp, _sz, _vp, _sz, _f, _f, _f, _f, _i, _i, _vp, _sz, _vp, _sz, _vp],
     "gf_remap_linear_c3": [_vp, _i, _vp, _i, _i, _sz, _vp, _i, _i, _sz, _vp, _sz, _vp, _sz, _i, _dp, _vp],
     "gf_remap_cubic_u8c3_f32maps": [_vp, _vp, _i, _i, _sz, _vp, _i, _i, _sz, _vp, _sz, _vp, _sz, _i, _dp, _vp],
-    "gf_undistort_rotate_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _dp, _vp],
-    "gf_undistort_rotate_blend_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _i, _i, _dp, _vp],
+    "gf_undistort_rotate_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _dp, _vp],
+    "gf_undistort_rotate_blend_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _i, _i, _dp, _vp],
     "gf_blend_accumulate": [_vp, _i, _vp, _vp, _d, _i, _sz, _vp],
     "gf_blend_finalize": [_vp, _i, _vp, _vp, _sz, _vp],
     "gf_get_cubic_table": [_vp],
+    "gf_lens_scale_host": [_dp, _dp, _sz, _dp],
 }
 
 _lib = None
@@ -99,20 +100,34 @@ def border_value(v):
     return arr
 
 
-def make_frame_xform(K, D, R, P):
-    """Host: (K, D, R, P) as handed to cv2.fisheye.initUndistortRectifyMap -> FrameXform."""
+def distortion(D):
+    """k1..k4 as a ctypes double[4] (missing coefficients are 0, as cv2 treats an empty D)."""
+    arr = (C.c_double * 4)(0.0, 0.0, 0.0, 0.0)
+    if D is not None:
+        Df = np.asarray(D, np.float64).reshape(-1)
+        for k in range(min(4, Df.size)):
+            arr[k] = float(Df[k])
+    return arr
+
+
+def make_frame_xform(K, R, P):
+    """Host: (K, R, P) as handed to cv2.fisheye.initUndistortRectifyMap -> FrameXform."""
     lib = load()
     Kc = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
-    Dv = np.zeros(4, np.float64)
-    Df = np.asarray(D, np.float64).reshape(-1)
-    Dv[:min(4, Df.size)] = Df[:4]
     Rc = np.ascontiguousarray(np.asarray(np.eye(3) if R is None else R, np.float64).reshape(9))
     Pc = np.ascontiguousarray(np.asarray(P, np.float64)[:, :3].reshape(9))
     out = FrameXform()
-    check(lib.gf_make_frame_xform(Kc.ctypes.data_as(_dp), Dv.ctypes.data_as(_dp), Rc.ctypes.data_as(_dp),
-                                  Pc.ctypes.data_as(_dp), C.byref(out)))
+    check(lib.gf_make_frame_xform(Kc.ctypes.data_as(_dp), Rc.ctypes.data_as(_dp), Pc.ctypes.data_as(_dp), C.byref(out)))
     return out
 
 
 def xform_to_array(xf):
     return np.frombuffer(bytes(xf), dtype=np.float64).copy()
+
+
+def lens_scale_host(D, t):
+    """Host: the kernels' table approximation of S(t) = theta_d(atan sqrt t)/sqrt t for an array of t."""
+    t = np.ascontiguousarray(np.asarray(t, np.float64).reshape(-1))
+    out = np.empty_like(t)
+    check(load().gf_lens_scale_host(distortion(D), t.ctypes.data_as(_dp), t.size, out.ctypes.data_as(_dp)))
+    return out

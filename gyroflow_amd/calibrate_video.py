@@ -149,14 +149,14 @@ class FisheyeCalibrator:
 
     # ------------------------------------------------------------------ fused-path parameters
     def frame_xform(self, fov_scale=1.0, output_dim=None, new_img_dim=None, quat=None, focalCenter=None):
-        """One gf_frame_xform row (17 float64) for cv.undistort_rotate: same parameters as get_maps()."""
+        """One gf_frame_xform row (13 float64) for cv.undistort_rotate (which also takes self.D): same parameters as get_maps()."""
         if self.image_is_stretched():
             raise NotImplementedError("stretched presets go through get_maps() + remap() (float32 map rescale)")
         scaled_K, D, R, new_K, _ = self._frame_matrices(fov_scale, output_dim, new_img_dim, quat, focalCenter, True)
-        return _lib.xform_to_array(_lib.make_frame_xform(scaled_K, D, R, new_K))
+        return _lib.xform_to_array(_lib.make_frame_xform(scaled_K, R, new_K))
 
     def frame_xforms(self, fov_scales, quats, output_dim=None, new_img_dim=None, focalCenters=None):
-        """[N,17] float64: frame_xform() for every (fov_scale[i], quat[i], focalCenter[i])."""
+        """[N,13] float64: frame_xform() for every (fov_scale[i], quat[i], focalCenter[i])."""
         quats = np.asarray(quats, np.float64)
         n = quats.shape[0]
         fov_scales = np.broadcast_to(np.asarray(fov_scales, np.float64), (n,))

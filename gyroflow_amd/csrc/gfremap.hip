@@ -5,12 +5,20 @@
 //   stabilizer.py:1423-1447     render-loop body            -> cv2.remap(INTER_LINEAR) + float64 blend
 //   nonlinear_stretch.py:130    apply_stretch               -> cv2.remap(INTER_CUBIC)
 //
-// Layout: one thread produces PXT=4 horizontally adjacent output pixels (12 B of u8 BGR = one
-// dwordx3 store; a wave64 writes two 384-B row segments = whole 128-B lines), a 256-thread
-// workgroup covers a 128x8 output tile, blockIdx.z is the frame.  The fixed-point map
-// (INTER_BITS=5) lives in registers only.  Source taps are gathered through L1/L2 with unaligned
-// dword loads (6 useful bytes per tap pair); workgroups are dealt to XCDs in contiguous bands of
-// tile rows so that each XCD's L2 sees one horizontal band of the source frame.
+// Design (DESIGN.md has the numbers):
+//  * The kernels are VALU-issue bound, not HBM bound, unless the per-pixel instruction count is cut hard, so the
+//    lens model is evaluated as  u = fx * (X/W) * S(t) + cx,  t = (X^2+Y^2)/W^2,  S(t) = theta_d(atan sqrt t)/sqrt t,
+//    with S read from a per-lens table of degree-5 polynomials (512 pieces, geometric in 1+t, 24 KB in LDS, relative
+//    error < 1e-14) and 1/W from v_rcp_f64 + one Newton step: 24 f64 ops per pixel instead of ~110 (atan, sqrt and
+//    three IEEE divisions).  Pixels whose ray leaves the table (more than ~86 degrees off axis, or behind the camera)
+//    take the exact formula.
+//  * u8 bilinear taps use v_dot4_u32_u8 on the raw loaded dwords (no byte unpacking): a horizontal pass with the
+//    5-bit x weights, then a vertical 24-bit mad pass -- the same integers as OpenCV's Q15 table.
+//  * One thread produces PXT=4 horizontally adjacent output pixels (12 B of u8 BGR = one dwordx3 store; a wave64
+//    writes two 384-B row segments = whole 128-B lines); a 256-thread workgroup covers a 128x32 output tile in four
+//    passes of 8 rows; blockIdx.y is the frame.  The fixed-point map (INTER_BITS=5) lives in registers only.
+//  * Source taps are gathered through L1/L2 with unaligned dword loads; workgroups are dealt to XCDs in contiguous
+//    bands of tile rows so that each XCD's L2 sees one horizontal band of the source frame.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -18,6 +26,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <mutex>
+#include <new>
 
 #include "../../include/gfremap.h"
 
@@ -27,9 +36,19 @@ constexpr int INTER_BITS = 5;
 constexpr int INTER_TAB_SIZE = 32;
 constexpr int PXT = 4;            // pixels per thread (horizontal)
 constexpr int TILE_W = 128;       // output tile width  (32 threads x 4 px)
-constexpr int TILE_H = 8;         // output tile height
+constexpr int TILE_H = 32;        // output tile height (4 passes of 8 rows)
+constexpr int PASS_H = 8;
 constexpr int BLOCK = 256;
 constexpr int NXCD = 8;
+
+// lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave, degree LENS_DEG
+constexpr int LENS_OCT = 8;
+constexpr int LENS_SUB_BITS = 6;
+constexpr int LENS_N = LENS_OCT << LENS_SUB_BITS;       // 512 pieces
+constexpr int LENS_COEF = 6;                            // degree 5
+constexpr int LENS_DOUBLES = LENS_N*LENS_COEF;          // 3072 doubles = 24576 B
+constexpr int LENS_SLOTS = 4;
+constexpr double ROUND_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: low dword of (x + magic) = rint(x), |x| < 2^31
 
 thread_local char g_err[512] = "";
 
@@ -45,9 +64,20 @@ int fail(int code, const char* fmt, const char* a = "", long long b = 0)
         if (e_ != hipSuccess) return fail(GF_ERR_HIP, "%s failed: HIP error %lld", #expr, (long long)e_); \
     } while (0)
 
+struct LensSlot {
+    double D[4];
+    bool valid;
+    double* dev;          // LENS_DOUBLES doubles
+    double* host;         // pinned staging
+    unsigned long long last_use;
+};
+
 struct Ctx {
     int device;
     int16_t* cubic_tab;   // device, 1024*16 int16 (cv2 INTER_CUBIC Q15 table)
+    LensSlot lens[LENS_SLOTS];
+    unsigned long long tick;
+    std::mutex mu;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -97,10 +127,73 @@ void build_cubic_host()
 }
 
 // ---------------------------------------------------------------------------------------------
+// Host: lens table.  S(t) = theta_d / r with r = sqrt(t), theta = atan r, theta_d = theta (1 + k1 theta^2 + ... +
+// k4 theta^8) is the radial scale of cv::fisheye::initUndistortRectifyMap (fisheye.cpp) as a function of
+// t = x^2 + y^2.  It is analytic in t with its nearest singularity at t = -1, so on pieces whose width is 1/64 of
+// their distance to that singularity (q = 1 + t split by binary exponent and the top 6 mantissa bits) a degree-5
+// interpolant at Chebyshev nodes is accurate to ~(1/256)^6 = 3.6e-15 relative.  Built in 80-bit long double.
+// Piece idx covers q in [2^e (1 + m/64), 2^e (1 + (m+1)/64)), e = idx >> 6, m = idx & 63; the polynomial variable is
+// z = (q - q_lo)/h - 0.5 in [-0.5, 0.5), which the kernel gets from q's mantissa bits without a division.
+
+long double lens_scale_ld(const double* D, long double t)
+{
+    if (t <= 0) return 1.0L;
+    const long double r = sqrtl(t), th = atanl(r), th2 = th*th;
+    return th*(1.0L + th2*((long double)D[0] + th2*((long double)D[1] + th2*((long double)D[2] + th2*(long double)D[3]))))/r;
+}
+
+void build_lens_table(const double* D, double* tab)
+{
+    long double zn[LENS_COEF];
+    for (int k = 0; k < LENS_COEF; k++) zn[k] = 0.5L*cosl(M_PIl*(2*k + 1)/(2.0L*LENS_COEF));
+    for (int idx = 0; idx < LENS_N; idx++) {
+        const int e = idx >> LENS_SUB_BITS, m = idx & ((1 << LENS_SUB_BITS) - 1);
+        const long double h = ldexpl(1.0L, e - LENS_SUB_BITS), qlo = ldexpl(1.0L, e) + m*h;
+        long double A[LENS_COEF][LENS_COEF + 1];
+        for (int k = 0; k < LENS_COEF; k++) {
+            long double p = 1;
+            for (int j = 0; j < LENS_COEF; j++) { A[k][j] = p; p *= zn[k]; }
+            A[k][LENS_COEF] = lens_scale_ld(D, qlo + (zn[k] + 0.5L)*h - 1.0L);
+        }
+        for (int c = 0; c < LENS_COEF; c++) {               // Gaussian elimination, partial pivoting
+            int piv = c;
+            for (int r = c + 1; r < LENS_COEF; r++) if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+            if (piv != c) for (int j = 0; j <= LENS_COEF; j++) { long double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+            for (int r = c + 1; r < LENS_COEF; r++) {
+                const long double f = A[r][c]/A[c][c];
+                for (int j = c; j <= LENS_COEF; j++) A[r][j] -= f*A[c][j];
+            }
+        }
+        long double a[LENS_COEF];
+        for (int r = LENS_COEF - 1; r >= 0; r--) {
+            long double s = A[r][LENS_COEF];
+            for (int j = r + 1; j < LENS_COEF; j++) s -= A[r][j]*a[j];
+            a[r] = s/A[r][r];
+        }
+        for (int j = 0; j < LENS_COEF; j++) tab[idx*LENS_COEF + j] = (double)a[j];
+    }
+}
+
+// the kernel's table lookup, restated for the host (gf_lens_scale_host; CPU tests check it against long double)
+double lens_eval_host(const double* tab, double q)
+{
+    uint64_t b; memcpy(&b, &q, 8);
+    const int hi = (int)(b >> 32);
+    const unsigned idx = (unsigned)((hi >> 14) - (1023 << 6));
+    if (!(idx < (unsigned)LENS_N)) return NAN;
+    const uint64_t zb = ((b << 6) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double zz; memcpy(&zz, &zb, 8);
+    const double zc = zz - 1.5;
+    const double* c = tab + idx*LENS_COEF;
+    double S = fma(c[5], zc, c[4]);
+    S = fma(S, zc, c[3]); S = fma(S, zc, c[2]); S = fma(S, zc, c[1]); S = fma(S, zc, c[0]);
+    return S;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Device helpers
 
 typedef uint32_t __attribute__((aligned(1))) u32_unaligned;
-typedef uint16_t __attribute__((aligned(1))) u16_unaligned;
 struct __attribute__((packed, aligned(2))) U16x6 { uint32_t a, b, c; };
 
 // cvRound(double) on x86-64 (cvtsd2si): round-half-even, INT_MIN when the result does not fit / NaN.
@@ -118,120 +211,155 @@ __device__ __forceinline__ int sat_s16(int v) { return v < -32768 ? -32768 : v >
 
 struct Xf {                // kernel-side copy of gf_frame_xform
     double iR[9];
-    double f[2], c[2], k[4];
+    double f[2], c[2];
 };
+struct LensK { double k[4]; };
 
-// Fixed-point source coordinate of output pixel (j, i): the per-pixel body of
-// cv::fisheye::initUndistortRectifyMap with m1type == CV_16SC2.  rx/ry/rw are the row terms
-// i*iR[.1] + iR[.2] (same two roundings as the reference loop's row start); the column term
-// uses one fma instead of j sequential additions (differs by < 1e-12 px).
-
-__device__ __forceinline__ void fisheye_uv(const Xf& xf, double rx, double ry, double rw, int j, double& u, double& v)
+// Exact per-pixel body of cv::fisheye::initUndistortRectifyMap: 32*u, 32*v from the homogeneous ray (_x,_y,_w).
+// Used where the table does not apply.  Never inlined: it is the cold path.
+__device__ __noinline__ double2 fisheye_uv32_exact(double f0, double f1, double c0, double c1, double k0, double k1, double k2, double k3,
+                                                   double _x, double _y, double _w)
 {
-    const double dj = (double)j;
-    const double _x = __fma_rn(dj, xf.iR[0], rx);
-    const double _y = __fma_rn(dj, xf.iR[3], ry);
-    const double _w = __fma_rn(dj, xf.iR[6], rw);
+    double u, v;
     if (_w <= 0) {
         u = (_x > 0) ? -INFINITY : INFINITY;
         v = (_y > 0) ? -INFINITY : INFINITY;
-        return;
+    } else {
+        const double x = _x/_w, y = _y/_w;
+        const double r = sqrt(x*x + y*y);
+        const double theta = atan(r);
+        const double t2 = theta*theta, t4 = t2*t2, t6 = t4*t2, t8 = t4*t4;
+        const double theta_d = theta*(1 + k0*t2 + k1*t4 + k2*t6 + k3*t8);
+        const double scale = (r == 0) ? 1.0 : theta_d/r;
+        u = f0*x*scale + c0;
+        v = f1*y*scale + c1;
     }
-    const double x = _x/_w, y = _y/_w;
-    const double r = sqrt(x*x + y*y);
-    const double theta = atan(r);
-    const double t2 = theta*theta, t4 = t2*t2, t6 = t4*t2, t8 = t4*t4;
-    const double theta_d = theta*(1 + xf.k[0]*t2 + xf.k[1]*t4 + xf.k[2]*t6 + xf.k[3]*t8);
-    const double scale = (r == 0) ? 1.0 : theta_d/r;
-    u = xf.f[0]*x*scale + xf.c[0];
-    v = xf.f[1]*y*scale + xf.c[1];
+    return make_double2(u*INTER_TAB_SIZE, v*INTER_TAB_SIZE);
 }
 
-__device__ __forceinline__ void row_terms(const Xf& xf, int i, double& rx, double& ry, double& rw)
+// Per-thread, per-(frame,row) constants of the coordinate computation.
+struct RowC {
+    double rx, ry, rw;        // i*iR[.1] + iR[.2]: the reference loop's row start (mul then add, two roundings)
+    double ax, ay, aw;        // iR[.0]: per-column step
+    double fx32, fy32, cx32, cy32;
+};
+
+__device__ __forceinline__ RowC row_consts(const Xf& xf, int i)
 {
+    RowC r;
     const double di = (double)i;
-    rx = __dadd_rn(__dmul_rn(di, xf.iR[1]), xf.iR[2]);
-    ry = __dadd_rn(__dmul_rn(di, xf.iR[4]), xf.iR[5]);
-    rw = __dadd_rn(__dmul_rn(di, xf.iR[7]), xf.iR[8]);
+    r.rx = __dadd_rn(__dmul_rn(di, xf.iR[1]), xf.iR[2]);
+    r.ry = __dadd_rn(__dmul_rn(di, xf.iR[4]), xf.iR[5]);
+    r.rw = __dadd_rn(__dmul_rn(di, xf.iR[7]), xf.iR[8]);
+    r.ax = xf.iR[0]; r.ay = xf.iR[3]; r.aw = xf.iR[6];
+    r.fx32 = xf.f[0]*32.0; r.fy32 = xf.f[1]*32.0; r.cx32 = xf.c[0]*32.0; r.cy32 = xf.c[1]*32.0;   // exact scalings
+    return r;
 }
 
-// (sx, sy, a) exactly as the CV_16SC2/CV_16UC1 pair would carry them: wrapping (short) cast of the
-// integer part, 10-bit fraction index a = fy*32 + fx.
-__device__ __forceinline__ void q5_from_uv(double u, double v, int& sx, int& sy, int& a)
+// 32*u, 32*v of output pixel column j through the lens table.  Returns false (tu/tv untouched) when the pixel needs
+// the exact formula: ray behind the camera (_w <= 0), t outside [0, 255), or NaN.
+// The column term uses one fma instead of the reference's j sequential additions (differs by < 1e-12 px).
+__device__ __forceinline__ bool coord_fast(const RowC& r, const double2* __restrict__ tab, int j, double& X, double& Y, double& W,
+                                           double& tu, double& tv)
 {
-    const int iu = cv_round_d(u*INTER_TAB_SIZE);
-    const int iv = cv_round_d(v*INTER_TAB_SIZE);
-    sx = (int)(int16_t)(iu >> INTER_BITS);
-    sy = (int)(int16_t)(iv >> INTER_BITS);
-    a = (iv & (INTER_TAB_SIZE-1))*INTER_TAB_SIZE + (iu & (INTER_TAB_SIZE-1));
+    const double dj = (double)j;
+#ifdef GF_ABL_NOMATH   /* tools/ ablation builds only: a cheap 3-degree rotation instead of the lens model */
+    X = Y = W = 1.0;
+    tu = (dj*1.003 + 2.3 + 0.05*r.rw)*32.0; tv = (r.rw*0.998 - dj*0.04 + 160.7)*32.0;
+    return true;
+#endif
+    X = __fma_rn(dj, r.ax, r.rx);
+    Y = __fma_rn(dj, r.ay, r.ry);
+    W = __fma_rn(dj, r.aw, r.rw);
+    double iw = __builtin_amdgcn_rcp(W);                       // v_rcp_f64: 2^-24.8 relative
+    iw = __fma_rn(__fma_rn(-W, iw, 1.0), iw, iw);              // one Newton step: ~2^-49
+    const double x = X*iw, y = Y*iw;
+    const double q = __fma_rn(x, x, __fma_rn(y, y, 1.0));      // 1 + t
+    const int hi = __double2hiint(q);
+    const unsigned idx = (unsigned)((hi >> (20 - LENS_SUB_BITS)) - (1023 << LENS_SUB_BITS));
+    if (!(idx < (unsigned)LENS_N && W > 0)) return false;
+    const unsigned lo = (unsigned)__double2loint(q);
+    const int zhi = (int)((__builtin_amdgcn_alignbit((unsigned)hi, lo, 32 - LENS_SUB_BITS) & 0x000FFFFFu) | 0x3FF00000u);
+    const double zc = __hiloint2double(zhi, (int)(lo << LENS_SUB_BITS)) - 1.5;
+    const double2 c01 = tab[idx*3], c23 = tab[idx*3 + 1], c45 = tab[idx*3 + 2];
+    double S = __fma_rn(c45.y, zc, c45.x);
+    S = __fma_rn(S, zc, c23.y); S = __fma_rn(S, zc, c23.x); S = __fma_rn(S, zc, c01.y); S = __fma_rn(S, zc, c01.x);
+    tu = __fma_rn(x*S, r.fx32, r.cx32);
+    tv = __fma_rn(y*S, r.fy32, r.cy32);
+    return true;
+}
+
+// Q5 integers of one pixel, fast or exact.
+__device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const LensK& lk, const double2* __restrict__ tab, int j,
+                                         int& iu, int& iv)
+{
+    double X, Y, W, tu, tv;
+    if (coord_fast(r, tab, j, X, Y, W, tu, tv)) {
+        iu = __double2loint(tu + ROUND_MAGIC);
+        iv = __double2loint(tv + ROUND_MAGIC);
+    } else {
+        const double2 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
+        iu = cv_round_d(o.x); iv = cv_round_d(o.y);
+    }
+}
+
+__device__ __forceinline__ void load_lens_table(const double* __restrict__ g, double2* s_tab)
+{
+    const double2* g2 = (const double2*)g;
+#pragma unroll
+    for (int k = 0; k < LENS_DOUBLES/2/BLOCK; k++) s_tab[threadIdx.x + k*BLOCK] = g2[threadIdx.x + k*BLOCK];
+    __syncthreads();
 }
 
 struct SrcImg {
     const uint8_t* base;   // frame base (bytes)
     int w, h;
-    long step;             // bytes
+    unsigned step;         // bytes (< 2^24; frame < 2^31 bytes)
 };
 
 template <int DEPTH> struct PixT;
 template <> struct PixT<GF_DEPTH_U8>  { typedef uint8_t  T; };
 template <> struct PixT<GF_DEPTH_U16> { typedef uint16_t T; };
 
-// One bilinear output pixel, cv::remapBilinear semantics (imgwarp.cpp).  Returns false when the
-// pixel must be left untouched (BORDER_TRANSPARENT outside).  out[3] receives the channel values.
+// One bilinear output pixel, cv::remapBilinear semantics (imgwarp.cpp), any border case.  (sx, sy) are the map's
+// int16 coordinates, a = fy*32 + fx.  Returns false when the pixel must be left untouched (BORDER_TRANSPARENT
+// outside).  This is the general (slow) path; interior pixels go through interp4_fast_*.
+struct Px3 { int c0, c1, c2, ok; };
+
 template <int DEPTH, int BORDER>
-__device__ __forceinline__ bool bilinear_px(const SrcImg& s, int sx, int sy, int a, const int* cval, int* out)
+__device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0, int cv1, int cv2)
 {
     typedef typename PixT<DEPTH>::T T;
+    const int cval[3] = {cv0, cv1, cv2};
+    int out[3];
     const int fx = a & 31, fy = a >> 5;
     int p[4][3];                                    // taps: 00, 01, 10, 11
+    int x0 = sx, x1 = sx + 1, y0 = sy, y1 = sy + 1;
+    bool vx0 = true, vx1 = true, vy0 = true, vy1 = true;
     const bool inlier = (unsigned)sx < (unsigned)(s.w - 1) && (unsigned)sy < (unsigned)(s.h - 1);
-    if (inlier) {
-        const uint8_t* q = s.base + (long)sy*s.step + (long)sx*(3*(int)sizeof(T));
-        if (DEPTH == GF_DEPTH_U8) {
-            // 6 bytes per row pair: two overlapping unaligned dwords (bytes 0..3 and 2..5) -- never
-            // reads past the last byte of the frame.
-            const uint32_t a0 = *(const u32_unaligned*)q,            a1 = *(const u32_unaligned*)(q + 2);
-            const uint32_t b0 = *(const u32_unaligned*)(q + s.step), b1 = *(const u32_unaligned*)(q + s.step + 2);
-            p[0][0] = a0 & 0xff; p[0][1] = (a0 >> 8) & 0xff;  p[0][2] = (a0 >> 16) & 0xff;
-            p[1][0] = a0 >> 24;  p[1][1] = (a1 >> 16) & 0xff; p[1][2] = a1 >> 24;
-            p[2][0] = b0 & 0xff; p[2][1] = (b0 >> 8) & 0xff;  p[2][2] = (b0 >> 16) & 0xff;
-            p[3][0] = b0 >> 24;  p[3][1] = (b1 >> 16) & 0xff; p[3][2] = b1 >> 24;
-        } else {
-            U16x6 r0, r1;                                              // 12 bytes per row pair
-            __builtin_memcpy(&r0, q, 12);
-            __builtin_memcpy(&r1, q + s.step, 12);
-            p[0][0] = r0.a & 0xffff; p[0][1] = r0.a >> 16; p[0][2] = r0.b & 0xffff;
-            p[1][0] = r0.b >> 16;    p[1][1] = r0.c & 0xffff; p[1][2] = r0.c >> 16;
-            p[2][0] = r1.a & 0xffff; p[2][1] = r1.a >> 16; p[2][2] = r1.b & 0xffff;
-            p[3][0] = r1.b >> 16;    p[3][1] = r1.c & 0xffff; p[3][2] = r1.c >> 16;
-        }
-    } else {
-        int x0 = sx, x1 = sx + 1, y0 = sy, y1 = sy + 1;
-        bool vx0, vx1, vy0, vy1;
+    if (!inlier) {
         if (BORDER == GF_BORDER_CONSTANT) {
             if (sx >= s.w || sx + 1 < 0 || sy >= s.h || sy + 1 < 0) {
-                out[0] = cval[0]; out[1] = cval[1]; out[2] = cval[2];
-                return true;
+                return Px3{cv0, cv1, cv2, 1};
             }
             vx0 = (unsigned)x0 < (unsigned)s.w; vx1 = (unsigned)x1 < (unsigned)s.w;
             vy0 = (unsigned)y0 < (unsigned)s.h; vy1 = (unsigned)y1 < (unsigned)s.h;
         } else if (BORDER == GF_BORDER_TRANSPARENT) {
-            return false;                           // (unsigned)sx >= w-1 || (unsigned)sy >= h-1
+            return Px3{0, 0, 0, 0};                 // (unsigned)sx >= w-1 || (unsigned)sy >= h-1
         } else {                                    // REPLICATE: clamp
             x0 = min(max(x0, 0), s.w - 1); x1 = min(max(x1, 0), s.w - 1);
             y0 = min(max(y0, 0), s.h - 1); y1 = min(max(y1, 0), s.h - 1);
-            vx0 = vx1 = vy0 = vy1 = true;
         }
-        const int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
-        const bool vs[4] = {vx0 && vy0, vx1 && vy0, vx0 && vy1, vx1 && vy1};
+    }
+    const int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};
+    const bool vs[4] = {vx0 && vy0, vx1 && vy0, vx0 && vy1, vx1 && vy1};
 #pragma unroll
-        for (int t = 0; t < 4; t++) {
-            if (vs[t]) {
-                const T* q = (const T*)(s.base + (long)ys[t]*s.step) + xs[t]*3;
-                p[t][0] = q[0]; p[t][1] = q[1]; p[t][2] = q[2];
-            } else {
-                p[t][0] = cval[0]; p[t][1] = cval[1]; p[t][2] = cval[2];
-            }
+    for (int t = 0; t < 4; t++) {
+        if (vs[t]) {
+            const T* q = (const T*)(s.base + (size_t)ys[t]*s.step) + xs[t]*3;
+            p[t][0] = q[0]; p[t][1] = q[1]; p[t][2] = q[2];
+        } else {
+            p[t][0] = cval[0]; p[t][1] = cval[1]; p[t][2] = cval[2];
         }
     }
     if (DEPTH == GF_DEPTH_U8) {
@@ -256,7 +384,93 @@ __device__ __forceinline__ bool bilinear_px(const SrcImg& s, int sx, int sy, int
             out[c] = r < 0 ? 0 : r > 65535 ? 65535 : r;
         }
     }
-    return true;
+    return Px3{out[0], out[1], out[2], 1};
+}
+
+// Interior pixel, u8: sx in [0, w-2], sy in [0, h-2].  Two unaligned dwords per source row cover the 6 bytes
+// B0 G0 R0 B1 G1 R1 (bytes 0..3 and 2..5: never past the frame's last byte).  Horizontal pass with v_dot4_u32_u8 on
+// the raw dwords (weights 32-fx | fx placed on the bytes that hold the channel), vertical pass with 24-bit mads:
+// exactly sum(S * wy * wx), then (sum + 512) >> 10  ==  OpenCV's (sum(S * w_q15) + 2^14) >> 15.
+__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+{
+#ifdef GF_ABL_NOGATHER   /* tools/ ablation builds only: every tap hits the same cache line */
+    const unsigned off = ((sx ^ sy) & 3)*4;
+#else
+    const unsigned off = __umul24(sy, step) + __umul24(sx, 3);
+#endif
+    const uint8_t* q = base + off;
+    const uint32_t a0 = *(const u32_unaligned*)q,          a1 = *(const u32_unaligned*)(q + 2);
+    const uint32_t b0 = *(const u32_unaligned*)(q + step), b1 = *(const u32_unaligned*)(q + step + 2);
+    const unsigned wx0 = 32 - fx;
+    const unsigned wbr = wx0 | ((unsigned)fx << 24);            // bytes 0 and 3: B0,B1 of a0 / R0,R1 of a1
+    const unsigned wg0 = wx0 << 8, wg1 = (unsigned)fx << 16;    // G0 = byte 1 of a0, G1 = byte 2 of a1
+    const unsigned tB = __builtin_amdgcn_udot4(a0, wbr, 0u, false), bB = __builtin_amdgcn_udot4(b0, wbr, 0u, false);
+    const unsigned tR = __builtin_amdgcn_udot4(a1, wbr, 0u, false), bR = __builtin_amdgcn_udot4(b1, wbr, 0u, false);
+    const unsigned tG = __builtin_amdgcn_udot4(a1, wg1, __builtin_amdgcn_udot4(a0, wg0, 0u, false), false);
+    const unsigned bG = __builtin_amdgcn_udot4(b1, wg1, __builtin_amdgcn_udot4(b0, wg0, 0u, false), false);
+    const unsigned wy0 = 32 - fy;
+    out[0] = (int)((__umul24(bB, fy) + (__umul24(tB, wy0) + 512u)) >> 10);
+    out[1] = (int)((__umul24(bG, fy) + (__umul24(tG, wy0) + 512u)) >> 10);
+    out[2] = (int)((__umul24(bR, fy) + (__umul24(tR, wy0) + 512u)) >> 10);
+}
+
+// Interior pixel, u16: OpenCV's float path -- float32 weights, ((p00 w00 + p01 w01) + p10 w10) + p11 w11 with every
+// product and sum rounded (no FMA), cvRound, saturate.
+__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+{
+#ifdef GF_ABL_NOGATHER
+    const unsigned off = ((sx ^ sy) & 3)*4;
+#else
+    const unsigned off = __umul24(sy, step) + __umul24(sx, 6);
+#endif
+    const uint8_t* q = base + off;
+    U16x6 r0, r1;                                              // 12 bytes per source row: two pixels
+    __builtin_memcpy(&r0, q, 12);
+    __builtin_memcpy(&r1, q + step, 12);
+    const float wy1 = fy*(1.f/32), wy0 = 1.f - wy1, wx1 = fx*(1.f/32), wx0 = 1.f - wx1;
+    const float w00 = wy0*wx0, w01 = wy0*wx1, w10 = wy1*wx0, w11 = wy1*wx1;
+    const unsigned p00[3] = {r0.a & 0xffff, r0.a >> 16, r0.b & 0xffff}, p01[3] = {r0.b >> 16, r0.c & 0xffff, r0.c >> 16};
+    const unsigned p10[3] = {r1.a & 0xffff, r1.a >> 16, r1.b & 0xffff}, p11[3] = {r1.b >> 16, r1.c & 0xffff, r1.c >> 16};
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float t = __fmul_rn((float)p00[c], w00);
+        t = __fadd_rn(t, __fmul_rn((float)p01[c], w01));
+        t = __fadd_rn(t, __fmul_rn((float)p10[c], w10));
+        t = __fadd_rn(t, __fmul_rn((float)p11[c], w11));
+        const int r = (int)rintf(t);
+        out[c] = min(r, 65535);                                 // t >= 0 always
+    }
+}
+
+// PXT pixels of one thread from their Q5 coordinates (iu, iv) = rint(32 u), rint(32 v).  The CV_16SC2 map would carry
+// (short)(iu >> 5): whenever the unwrapped value is inside the image it equals the wrapped one, so the interior test
+// runs on the unwrapped integers and only the general path applies the wrap.  Returns the keep mask.
+template <int DEPTH, int BORDER>
+__device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const int* iv, const int* cval, int (*px)[3])
+{
+    const unsigned w1 = (unsigned)(s.w - 1), h1 = (unsigned)(s.h - 1);
+    bool all_in = true;
+#pragma unroll
+    for (int i = 0; i < PXT; i++)
+        all_in = all_in && (unsigned)(iu[i] >> INTER_BITS) < w1 && (unsigned)(iv[i] >> INTER_BITS) < h1;
+    unsigned keep = 0;
+    if (all_in) {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            if (DEPTH == GF_DEPTH_U8) interp_u8_interior(s.base, s.step, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+            else                      interp_u16_interior(s.base, s.step, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const int sx = (int)(int16_t)(iu[i] >> INTER_BITS), sy = (int)(int16_t)(iv[i] >> INTER_BITS);   // Q1: wrapping cast
+            const int a = (iv[i] & 31)*32 + (iu[i] & 31);
+            const Px3 o = bilinear_px<DEPTH, BORDER>(s, sx, sy, a, cval[0], cval[1], cval[2]);
+            if (!o.ok) keep |= 1u << i;
+            px[i][0] = o.c0; px[i][1] = o.c1; px[i][2] = o.c2;
+        }
+    }
+    return keep;
 }
 
 // Store PXT pixels (3 channels each) of one thread.  `keep` bit i set = pixel i untouched.
@@ -269,7 +483,7 @@ __device__ __forceinline__ void store_px(uint8_t* drow, int x0, int dw, const in
             uint32_t w0 = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
             uint32_t w1 = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
             uint32_t w2 = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
-            uint32_t* d = (uint32_t*)(drow + (long)x0*3);
+            uint32_t* d = (uint32_t*)(drow + (size_t)x0*3);
             struct alignas(4) W3 { uint32_t a, b, c; };
             *(W3*)d = W3{w0, w1, w2};
         } else {
@@ -279,13 +493,13 @@ __device__ __forceinline__ void store_px(uint8_t* drow, int x0, int dw, const in
                 const int e = i*2;          // element index in the 12-element run
                 w[i] = (uint32_t)px[e/3][e%3] | ((uint32_t)px[(e+1)/3][(e+1)%3] << 16);
             }
-            uint32_t* d = (uint32_t*)(drow + (long)x0*6);
+            uint32_t* d = (uint32_t*)(drow + (size_t)x0*6);
             struct alignas(8) W2 { uint32_t a, b; };
             *(W2*)(d) = W2{w[0], w[1]}; *(W2*)(d + 2) = W2{w[2], w[3]}; *(W2*)(d + 4) = W2{w[4], w[5]};
         }
         return;
     }
-    T* d = (T*)drow + (long)x0*3;
+    T* d = (T*)drow + (size_t)x0*3;
 #pragma unroll
     for (int i = 0; i < PXT; i++)
         if (x0 + i < dw && !((keep >> i) & 1)) {
@@ -307,8 +521,8 @@ __device__ __forceinline__ void tile_of_block(int bid, int tiles_x, int tiles_y,
 }
 
 struct RemapArgs {
-    const uint8_t* src; int sw, sh; long sstep, sframe;
-    uint8_t* dst; int dw, dh; long dstep, dframe;
+    const uint8_t* src; int sw, sh; unsigned sstep; size_t sframe;
+    uint8_t* dst; int dw, dh; size_t dstep, dframe;
     int tiles_x, tiles_y;
     int cval[3];
     int dst_vec_ok;        // dst base/step/frame stride allow 4-byte (u8) / 8-byte (u16) vector stores
@@ -316,134 +530,160 @@ struct RemapArgs {
 
 // K1: fused fisheye map + rotation + bilinear remap, batched over frames (blockIdx.y).
 template <int DEPTH, int BORDER>
-__global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs)
+__global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk)
 {
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
+    load_lens_table(lens, s_tab);
     int tx, ty;
     tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
     const int frame = blockIdx.y;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = tx*TILE_W + lx*PXT, y = ty*TILE_H + ly;
-    if (y >= A.dh || x0 >= A.dw) return;
+    const int x0 = tx*TILE_W + lx*PXT;
+    if (x0 >= A.dw) return;
     const Xf& xf = xfs[frame];
-    SrcImg s{A.src + (long)frame*A.sframe, A.sw, A.sh, A.sstep};
-    double rx, ry, rw;
-    row_terms(xf, y, rx, ry, rw);
-    int px[PXT][3];
-    unsigned keep = 0;
+    const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+#pragma unroll 1
+    for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
+        const int y = ty*TILE_H + pass*PASS_H + ly;
+        if (y >= A.dh) break;
+        const RowC rc = row_consts(xf, y);
+        int iu[PXT], iv[PXT];
 #pragma unroll
-    for (int i = 0; i < PXT; i++) {
-        double u, v; int sx, sy, a;
-        fisheye_uv(xf, rx, ry, rw, x0 + i, u, v);
-        q5_from_uv(u, v, sx, sy, a);
-        if (!bilinear_px<DEPTH, BORDER>(s, sx, sy, a, A.cval, px[i])) keep |= 1u << i;
+        for (int i = 0; i < PXT; i++) coord_q5(rc, xf, lk, s_tab, x0 + i, iu[i], iv[i]);
+        int px[PXT][3];
+        const unsigned keep = remap4<DEPTH, BORDER>(s, iu, iv, A.cval, px);
+        uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+        store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
     }
-    uint8_t* drow = A.dst + (long)frame*A.dframe + (long)y*A.dstep;
-    store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
 }
 
 // K1b: fused + hyperlapse blend: out = trunc(sum_b (1/N) * remap_b) in float64, reference order.
 template <int DEPTH, int BORDER>
-__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, const Xf* __restrict__ xfs,
-                                                                   int frames_per_group, int n_blend)
+__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens,
+                                                                   LensK lk, int frames_per_group, int n_blend)
 {
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
+    load_lens_table(lens, s_tab);
     int tx, ty;
     tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
     const int g = blockIdx.y;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = tx*TILE_W + lx*PXT, y = ty*TILE_H + ly;
-    if (y >= A.dh || x0 >= A.dw) return;
+    const int x0 = tx*TILE_W + lx*PXT;
+    if (x0 >= A.dw) return;
     const double wgt = 1.0/(double)n_blend;       // Python: 1/(self.hyperlapse_num_blended_frames)
-    double acc[PXT][3];
+#pragma unroll 1
+    for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
+        const int y = ty*TILE_H + pass*PASS_H + ly;
+        if (y >= A.dh) break;
+        double acc[PXT][3];
 #pragma unroll
-    for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0.0;
-    for (int b = 0; b < n_blend; b++) {
-        const int frame = g*frames_per_group + b;
-        const Xf& xf = xfs[frame];
-        SrcImg s{A.src + (long)frame*A.sframe, A.sw, A.sh, A.sstep};
-        double rx, ry, rw;
-        row_terms(xf, y, rx, ry, rw);
+        for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0.0;
+#pragma unroll 1
+        for (int b = 0; b < n_blend; b++) {
+            const int frame = g*frames_per_group + b;
+            const Xf& xf = xfs[frame];
+            const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+            const RowC rc = row_consts(xf, y);
+            int iu[PXT], iv[PXT], o[PXT][3];
 #pragma unroll
-        for (int i = 0; i < PXT; i++) {
-            double u, v; int sx, sy, a; int o[3];
-            fisheye_uv(xf, rx, ry, rw, x0 + i, u, v);
-            q5_from_uv(u, v, sx, sy, a);
-            bilinear_px<DEPTH, BORDER>(s, sx, sy, a, A.cval, o);
+            for (int i = 0; i < PXT; i++) coord_q5(rc, xf, lk, s_tab, x0 + i, iu[i], iv[i]);
+            remap4<DEPTH, BORDER>(s, iu, iv, A.cval, o);
 #pragma unroll
-            for (int c = 0; c < 3; c++) acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[c]));
+            for (int i = 0; i < PXT; i++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[i][c]));
         }
+        int px[PXT][3];
+#pragma unroll
+        for (int i = 0; i < PXT; i++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) px[i][c] = (int)acc[i][c];      // astype(uint): truncation
+        uint8_t* drow = A.dst + (size_t)g*A.dframe + (size_t)y*A.dstep;
+        store_px<DEPTH>(drow, x0, A.dw, px, 0u, A.dst_vec_ok);
     }
-    int px[PXT][3];
-#pragma unroll
-    for (int i = 0; i < PXT; i++)
-#pragma unroll
-        for (int c = 0; c < 3; c++) px[i][c] = (int)acc[i][c];      // astype(uint): truncation
-    uint8_t* drow = A.dst + (long)g*A.dframe + (long)y*A.dstep;
-    store_px<DEPTH>(drow, x0, A.dw, px, 0u, A.dst_vec_ok);
 }
 
 // K4: remap from materialised CV_16SC2 + CV_16UC1 maps.
 template <int DEPTH, int BORDER>
-__global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8_t* __restrict__ map1, long m1step,
-                                                         const uint8_t* __restrict__ map2, long m2step)
+__global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8_t* __restrict__ map1, size_t m1step,
+                                                         const uint8_t* __restrict__ map2, size_t m2step)
 {
     int tx, ty;
     tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = tx*TILE_W + lx*PXT, y = ty*TILE_H + ly;
-    if (y >= A.dh || x0 >= A.dw) return;
-    SrcImg s{A.src, A.sw, A.sh, A.sstep};
-    const int16_t* m1 = (const int16_t*)(map1 + (long)y*m1step);
-    const uint16_t* m2 = (const uint16_t*)(map2 + (long)y*m2step);
-    int px[PXT][3];
-    unsigned keep = 0;
+    const int x0 = tx*TILE_W + lx*PXT;
+    if (x0 >= A.dw) return;
+    const SrcImg s{A.src, A.sw, A.sh, A.sstep};
+#pragma unroll 1
+    for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
+        const int y = ty*TILE_H + pass*PASS_H + ly;
+        if (y >= A.dh) break;
+        const int16_t* m1 = (const int16_t*)(map1 + (size_t)y*m1step);
+        const uint16_t* m2 = (const uint16_t*)(map2 + (size_t)y*m2step);
+        int iu[PXT], iv[PXT];
 #pragma unroll
-    for (int i = 0; i < PXT; i++) {
-        const int x = min(x0 + i, A.dw - 1);
-        const int sx = m1[x*2], sy = m1[x*2+1], a = m2[x] & 1023;
-        if (!bilinear_px<DEPTH, BORDER>(s, sx, sy, a, A.cval, px[i])) keep |= 1u << i;
+        for (int i = 0; i < PXT; i++) {
+            const int x = min(x0 + i, A.dw - 1);
+            const int a = m2[x] & 1023;
+            iu[i] = ((int)m1[x*2] << INTER_BITS) | (a & 31);          // back to the Q5 integers the map was made from
+            iv[i] = ((int)m1[x*2+1] << INTER_BITS) | (a >> 5);
+        }
+        int px[PXT][3];
+        const unsigned keep = remap4<DEPTH, BORDER>(s, iu, iv, A.cval, px);
+        uint8_t* drow = A.dst + (size_t)y*A.dstep;
+        store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
     }
-    uint8_t* drow = A.dst + (long)y*A.dstep;
-    store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
 }
 
-// K2: materialised maps.  One thread per output pixel, 64x4 tiles.
+// K2: materialised maps.  One thread per output pixel and pass, 64 x 32 tiles.
 template <bool FIXED>
-__global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, int w, int h, uint8_t* map1, long m1step, uint8_t* map2, long m2step)
+__global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const double* __restrict__ lens, int w, int h,
+                                                         uint8_t* map1, size_t m1step, uint8_t* map2, size_t m2step)
 {
-    const int j = blockIdx.x*64 + (threadIdx.x & 63), i = blockIdx.y*4 + (threadIdx.x >> 6);
-    if (j >= w || i >= h) return;
-    double rx, ry, rw, u, v;
-    row_terms(xf, i, rx, ry, rw);
-    fisheye_uv(xf, rx, ry, rw, j, u, v);
-    if (FIXED) {
-        const int iu = cv_round_d(u*INTER_TAB_SIZE), iv = cv_round_d(v*INTER_TAB_SIZE);
-        int16_t* m1 = (int16_t*)(map1 + (long)i*m1step);
-        uint16_t* m2 = (uint16_t*)(map2 + (long)i*m2step);
-        // one 4-byte store for the (x,y) pair
-        *(uint32_t*)(m1 + 2*j) = (uint32_t)(uint16_t)(iu >> INTER_BITS) | ((uint32_t)(uint16_t)(iv >> INTER_BITS) << 16);
-        m2[j] = (uint16_t)((iv & 31)*32 + (iu & 31));
-    } else {
-        ((float*)(map1 + (long)i*m1step))[j] = (float)u;
-        ((float*)(map2 + (long)i*m2step))[j] = (float)v;
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
+    load_lens_table(lens, s_tab);
+    const int j = blockIdx.x*64 + (threadIdx.x & 63);
+    if (j >= w) return;
+#pragma unroll 1
+    for (int pass = 0; pass < 8; pass++) {
+        const int i = blockIdx.y*32 + pass*4 + (threadIdx.x >> 6);
+        if (i >= h) break;
+        const RowC rc = row_consts(xf, i);
+        if (FIXED) {
+            int iu, iv;
+            coord_q5(rc, xf, lk, s_tab, j, iu, iv);
+            int16_t* m1 = (int16_t*)(map1 + (size_t)i*m1step);
+            uint16_t* m2 = (uint16_t*)(map2 + (size_t)i*m2step);
+            // one 4-byte store for the (x,y) pair; (short) cast wraps (Q1)
+            *(uint32_t*)(m1 + 2*j) = (uint32_t)(uint16_t)(iu >> INTER_BITS) | ((uint32_t)(uint16_t)(iv >> INTER_BITS) << 16);
+            m2[j] = (uint16_t)((iv & 31)*32 + (iu & 31));
+        } else {
+            double X, Y, W;
+            double2 o;
+            if (!coord_fast(rc, s_tab, j, X, Y, W, o.x, o.y))
+                o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
+            ((float*)(map1 + (size_t)i*m1step))[j] = (float)(o.x*(1.0/32));
+            ((float*)(map2 + (size_t)i*m2step))[j] = (float)(o.y*(1.0/32));
+        }
     }
 }
 
 // K3: convertMaps(32F,32F -> 16SC2) with the reference's float32 pre-scaling.
-__global__ void __launch_bounds__(BLOCK) k_convert_maps(const uint8_t* mx, long mxstep, const uint8_t* my, long mystep,
+__global__ void __launch_bounds__(BLOCK) k_convert_maps(const uint8_t* mx, size_t mxstep, const uint8_t* my, size_t mystep,
                                                         float sxn, float sxd, float syn, float syd, int scale_on,
-                                                        int w, int h, uint8_t* map1, long m1step, uint8_t* map2, long m2step)
+                                                        int w, int h, uint8_t* map1, size_t m1step, uint8_t* map2, size_t m2step)
 {
     const int j = blockIdx.x*64 + (threadIdx.x & 63), i = blockIdx.y*4 + (threadIdx.x >> 6);
     if (j >= w || i >= h) return;
-    float fx = ((const float*)(mx + (long)i*mxstep))[j], fy = ((const float*)(my + (long)i*mystep))[j];
+    float fx = ((const float*)(mx + (size_t)i*mxstep))[j], fy = ((const float*)(my + (size_t)i*mystep))[j];
     if (scale_on) {
         fx = __fdiv_rn(__fmul_rn(fx, sxn), sxd);
         fy = __fdiv_rn(__fmul_rn(fy, syn), syd);
     }
     const int ix = cv_round_f(__fmul_rn(fx, 32.f)), iy = cv_round_f(__fmul_rn(fy, 32.f));
-    int16_t* m1 = (int16_t*)(map1 + (long)i*m1step);
+    int16_t* m1 = (int16_t*)(map1 + (size_t)i*m1step);
     *(uint32_t*)(m1 + 2*j) = (uint32_t)(uint16_t)sat_s16(ix >> INTER_BITS) | ((uint32_t)(uint16_t)sat_s16(iy >> INTER_BITS) << 16);
-    ((uint16_t*)(map2 + (long)i*m2step))[j] = (uint16_t)((iy & 31)*32 + (ix & 31));
+    ((uint16_t*)(map2 + (size_t)i*m2step))[j] = (uint16_t)((iy & 31)*32 + (ix & 31));
 }
 
 // K5: cv::remapBicubic (u8c3, Q15 table) from float32 maps.  One thread per output pixel.
@@ -459,29 +699,29 @@ __device__ __forceinline__ int border_interp(int p, int len, int border1)
     return -1;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __restrict__ src, int sw, int sh, long sstep,
-                                                             uint8_t* dst, int dw, int dh, long dstep,
-                                                             const uint8_t* __restrict__ mx, long mxstep,
-                                                             const uint8_t* __restrict__ my, long mystep,
+__global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __restrict__ src, int sw, int sh, size_t sstep,
+                                                             uint8_t* dst, int dw, int dh, size_t dstep,
+                                                             const uint8_t* __restrict__ mx, size_t mxstep,
+                                                             const uint8_t* __restrict__ my, size_t mystep,
                                                              const int16_t* __restrict__ tab, int border, int c0, int c1, int c2)
 {
     const int dx = blockIdx.x*64 + (threadIdx.x & 63), dy = blockIdx.y*4 + (threadIdx.x >> 6);
     if (dx >= dw || dy >= dh) return;
-    const float fxm = ((const float*)(mx + (long)dy*mxstep))[dx], fym = ((const float*)(my + (long)dy*mystep))[dx];
+    const float fxm = ((const float*)(mx + (size_t)dy*mxstep))[dx], fym = ((const float*)(my + (size_t)dy*mystep))[dx];
     const int isx = cv_round_f(__fmul_rn(fxm, 32.f)), isy = cv_round_f(__fmul_rn(fym, 32.f));
     const int a = (isy & 31)*32 + (isx & 31);
     const int sx = sat_s16(isx >> INTER_BITS) - 1, sy = sat_s16(isy >> INTER_BITS) - 1;
     const int16_t* w = tab + a*16;
-    uint8_t* D = dst + (long)dy*dstep + dx*3;
+    uint8_t* D = dst + (size_t)dy*dstep + dx*3;
     const int cval[3] = {c0, c1, c2};
     const unsigned width1 = max(sw - 3, 0), height1 = max(sh - 3, 0);
     if ((unsigned)sx < width1 && (unsigned)sy < height1) {
-        const uint8_t* S = src + (long)sy*sstep + sx*3;
+        const uint8_t* S = src + (size_t)sy*sstep + sx*3;
         int sum[3] = {0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            // 12 bytes = 4 pixels x 3 channels: three overlapping-free unaligned dwords, all inside the row
-            const uint8_t* q = S + (long)r*sstep;
+            // 12 bytes = 4 pixels x 3 channels: three unaligned dwords, all inside the row
+            const uint8_t* q = S + (size_t)r*sstep;
             const uint32_t d0 = *(const u32_unaligned*)q, d1 = *(const u32_unaligned*)(q + 4), d2 = *(const u32_unaligned*)(q + 8);
             const int b[12] = {(int)(d0 & 0xff), (int)((d0 >> 8) & 0xff), (int)((d0 >> 16) & 0xff), (int)(d0 >> 24),
                                (int)(d1 & 0xff), (int)((d1 >> 8) & 0xff), (int)((d1 >> 16) & 0xff), (int)(d1 >> 24),
@@ -489,7 +729,7 @@ __global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __res
 #pragma unroll
             for (int t = 0; t < 4; t++) {
                 const int wt = w[r*4 + t];
-                sum[0] += b[t*3]*wt; sum[1] += b[t*3+1]*wt; sum[2] += b[t*3+2]*wt;
+                sum[0] += __mul24(b[t*3], wt); sum[1] += __mul24(b[t*3+1], wt); sum[2] += __mul24(b[t*3+2], wt);
             }
         }
 #pragma unroll
@@ -512,7 +752,7 @@ __global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __res
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             if (ys[i] < 0) continue;
-            const uint8_t* S = src + (long)ys[i]*sstep + k;
+            const uint8_t* S = src + (size_t)ys[i]*sstep + k;
 #pragma unroll
             for (int q = 0; q < 4; q++)
                 if (xs[q] >= 0) sum += ((int)S[xs[q]*3] - cv)*w[i*4 + q];
@@ -548,6 +788,8 @@ int check_img(const char* what, const void* p, int w, int h, size_t step, int de
     if (w <= 0 || h <= 0 || w >= SHRT_MAX || h >= SHRT_MAX) return fail(GF_ERR_INVALID_ARG, "%s: bad dimensions (must be 1..32766), w=%lld", what, w);
     if (step < (size_t)w*3*esz) return fail(GF_ERR_INVALID_ARG, "%s: row step %lld smaller than a row", what, (long long)step);
     if (esz == 2 && ((step & 1) || ((uintptr_t)p & 1))) return fail(GF_ERR_INVALID_ARG, "%s: u16 image must be 2-byte aligned", what);
+    if (step >= (1u << 24) || step*(size_t)h >= ((size_t)1 << 31))
+        return fail(GF_ERR_UNSUPPORTED, "%s: frames of 2 GiB or more (or rows of 16 MiB or more) are not supported (step=%lld)", what, (long long)step);
     return GF_OK;
 }
 
@@ -579,8 +821,8 @@ RemapArgs make_args(int depth, const void* src, int sw, int sh, size_t sstep, si
                     void* dst, int dw, int dh, size_t dstep, size_t dframe, const double* bv)
 {
     RemapArgs A;
-    A.src = (const uint8_t*)src; A.sw = sw; A.sh = sh; A.sstep = (long)sstep; A.sframe = (long)sframe;
-    A.dst = (uint8_t*)dst; A.dw = dw; A.dh = dh; A.dstep = (long)dstep; A.dframe = (long)dframe;
+    A.src = (const uint8_t*)src; A.sw = sw; A.sh = sh; A.sstep = (unsigned)sstep; A.sframe = sframe;
+    A.dst = (uint8_t*)dst; A.dw = dw; A.dh = dh; A.dstep = dstep; A.dframe = dframe;
     A.tiles_x = (dw + TILE_W - 1)/TILE_W; A.tiles_y = (dh + TILE_H - 1)/TILE_H;
     cval_from(bv, depth, A.cval);
     const size_t al = depth == GF_DEPTH_U8 ? 4 : 8;
@@ -609,6 +851,44 @@ Xf to_xf(const gf_frame_xform* x)
     return r;
 }
 
+// Device lens table for distortion coefficients D: a hit in the context's 4-slot cache costs nothing; a miss builds
+// the table on the host (~1 ms), uploads it on `stream` and waits for the upload (once per lens).
+int get_lens(Ctx* c, const double* D, hipStream_t stream, const double** dev, LensK* lk)
+{
+    if (!D) return fail(GF_ERR_INVALID_ARG, "%s: null distortion coefficients", "lens");
+    for (int i = 0; i < 4; i++) {
+        if (!(D[i] == D[i]) || fabs(D[i]) > 1e6) return fail(GF_ERR_INVALID_ARG, "lens: distortion coefficient %s%lld is not finite", "", i);
+        lk->k[i] = D[i];
+    }
+    std::lock_guard<std::mutex> g(c->mu);
+    c->tick++;
+    int lru = 0;
+    for (int i = 0; i < LENS_SLOTS; i++) {
+        LensSlot& s = c->lens[i];
+        if (s.valid && memcmp(s.D, D, sizeof s.D) == 0) { s.last_use = c->tick; *dev = s.dev; return GF_OK; }
+        if (!s.valid) { lru = i; break; }
+        if (s.last_use < c->lens[lru].last_use) lru = i;
+    }
+    LensSlot& s = c->lens[lru];
+    if (s.valid) {                       // evicting a table that launches on other streams may still be reading
+        HIP_TRY(hipDeviceSynchronize());
+        s.valid = false;
+    }
+    build_lens_table(D, s.host);
+    HIP_TRY(hipMemcpyAsync(s.dev, s.host, LENS_DOUBLES*sizeof(double), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    memcpy(s.D, D, sizeof s.D);
+    s.valid = true; s.last_use = c->tick;
+    *dev = s.dev;
+    return GF_OK;
+}
+
+struct DeviceGuard {
+    int prev; bool ok;
+    explicit DeviceGuard(int dev) : prev(0), ok(false) { if (hipGetDevice(&prev) == hipSuccess && (prev == dev || hipSetDevice(dev) == hipSuccess)) ok = true; }
+    ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -627,6 +907,17 @@ GF_API int gf_get_cubic_table(int16_t* out_host)
     return GF_OK;
 }
 
+GF_API int gf_lens_scale_host(const double D_host[4], const double* t_host, size_t n, double* out_host)
+{
+    if (!D_host || !t_host || !out_host) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_lens_scale_host");
+    double* tab = new (std::nothrow) double[LENS_DOUBLES];
+    if (!tab) return fail(GF_ERR_HIP, "%s: out of host memory", "gf_lens_scale_host");
+    build_lens_table(D_host, tab);
+    for (size_t i = 0; i < n; i++) out_host[i] = lens_eval_host(tab, 1.0 + t_host[i]);
+    delete[] tab;
+    return GF_OK;
+}
+
 GF_API int gf_ctx_create(int device, void** ctx)
 {
     if (!ctx) return fail(GF_ERR_INVALID_ARG, "%s: null ctx pointer", "gf_ctx_create");
@@ -634,19 +925,22 @@ GF_API int gf_ctx_create(int device, void** ctx)
     int ndev = 0;
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(GF_ERR_INVALID_ARG, "gf_ctx_create: device %s%lld out of range", "", device);
-    int prev = 0;
-    HIP_TRY(hipGetDevice(&prev));
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard dg(device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "gf_ctx_create: cannot select device %s%lld", "", device);
     std::call_once(g_cubic_once, build_cubic_host);
-    Ctx* c = new (std::nothrow) Ctx{device, nullptr};
+    Ctx* c = new (std::nothrow) Ctx();
     if (!c) return fail(GF_ERR_HIP, "%s: out of host memory", "gf_ctx_create");
+    c->device = device; c->cubic_tab = nullptr; c->tick = 0;
+    for (int i = 0; i < LENS_SLOTS; i++) { c->lens[i].valid = false; c->lens[i].dev = nullptr; c->lens[i].host = nullptr; c->lens[i].last_use = 0; }
     hipError_t e = hipMalloc((void**)&c->cubic_tab, sizeof g_cubic_host);
     if (e == hipSuccess) e = hipMemcpy(c->cubic_tab, g_cubic_host, sizeof g_cubic_host, hipMemcpyHostToDevice);
-    (void)hipSetDevice(prev);
+    for (int i = 0; i < LENS_SLOTS && e == hipSuccess; i++) {
+        e = hipMalloc((void**)&c->lens[i].dev, LENS_DOUBLES*sizeof(double));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&c->lens[i].host, LENS_DOUBLES*sizeof(double), hipHostMallocDefault);
+    }
     if (e != hipSuccess) {
-        if (c->cubic_tab) (void)hipFree(c->cubic_tab);
-        delete c;
-        return fail(GF_ERR_HIP, "gf_ctx_create: %s (HIP error %lld)", "table upload failed", (long long)e);
+        gf_ctx_destroy(c);
+        return fail(GF_ERR_HIP, "gf_ctx_create: %s (HIP error %lld)", "allocation/upload failed", (long long)e);
     }
     *ctx = c;
     return GF_OK;
@@ -657,13 +951,17 @@ GF_API int gf_ctx_destroy(void* ctx)
     if (!ctx) return GF_OK;
     Ctx* c = (Ctx*)ctx;
     if (c->cubic_tab) (void)hipFree(c->cubic_tab);
+    for (int i = 0; i < LENS_SLOTS; i++) {
+        if (c->lens[i].dev) (void)hipFree(c->lens[i].dev);
+        if (c->lens[i].host) (void)hipHostFree(c->lens[i].host);
+    }
     delete c;
     return GF_OK;
 }
 
-GF_API int gf_make_frame_xform(const double K[9], const double D[4], const double R[9], const double P[9], gf_frame_xform* out)
+GF_API int gf_make_frame_xform(const double K[9], const double R[9], const double P[9], gf_frame_xform* out)
 {
-    if (!K || !D || !R || !P || !out) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_make_frame_xform");
+    if (!K || !R || !P || !out) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_make_frame_xform");
     // PR = P*R (k ascending), iR = PR^-1 by the adjugate in long double, rounded once to double.
     long double m[9];
     for (int i = 0; i < 3; i++)
@@ -680,11 +978,10 @@ GF_API int gf_make_frame_xform(const double K[9], const double D[4], const doubl
     out->iR[3] = (double)(B*r); out->iR[4] = (double)((m[0]*m[8] - m[2]*m[6])*r);  out->iR[5] = (double)(-(m[0]*m[5] - m[2]*m[3])*r);
     out->iR[6] = (double)(C*r); out->iR[7] = (double)(-(m[0]*m[7] - m[1]*m[6])*r); out->iR[8] = (double)((m[0]*m[4] - m[1]*m[3])*r);
     out->f[0] = K[0]; out->f[1] = K[4]; out->c[0] = K[2]; out->c[1] = K[5];
-    for (int i = 0; i < 4; i++) out->k[i] = D[i];
     return GF_OK;
 }
 
-static int maps_common(void* ctx, const gf_frame_xform* xf, int w, int h, void* m1, size_t s1, void* m2, size_t s2,
+static int maps_common(void* ctx, const double* D, const gf_frame_xform* xf, int w, int h, void* m1, size_t s1, void* m2, size_t s2,
                        bool fixed, gf_stream_t stream)
 {
     if (!ctx) return fail(GF_ERR_INVALID_ARG, "%s: null ctx", "gf_fisheye_maps");
@@ -693,21 +990,25 @@ static int maps_common(void* ctx, const gf_frame_xform* xf, int w, int h, void* 
     const size_t min1 = (size_t)w*4, min2 = fixed ? (size_t)w*2 : (size_t)w*4;
     if (s1 < min1 || s2 < min2 || (s1 & 3) || (s2 & (fixed ? 1 : 3)) || ((uintptr_t)m1 & 3) || ((uintptr_t)m2 & (fixed ? 1 : 3)))
         return fail(GF_ERR_INVALID_ARG, "%s: map step/alignment invalid (step1=%lld)", "gf_fisheye_maps", (long long)s1);
-    dim3 grid((w + 63)/64, (h + 3)/4);
-    if (fixed) hipLaunchKernelGGL(k_fisheye_maps<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), w, h, (uint8_t*)m1, (long)s1, (uint8_t*)m2, (long)s2);
-    else       hipLaunchKernelGGL(k_fisheye_maps<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), w, h, (uint8_t*)m1, (long)s1, (uint8_t*)m2, (long)s2);
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    const double* lens; LensK lk;
+    int rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
+    dim3 grid((w + 63)/64, (h + 31)/32);
+    if (fixed) hipLaunchKernelGGL(k_fisheye_maps<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
+    else       hipLaunchKernelGGL(k_fisheye_maps<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
 
-GF_API int gf_fisheye_maps_16sc2(void* ctx, const gf_frame_xform* xf, int w, int h, int16_t* map1, size_t s1, uint16_t* map2, size_t s2, gf_stream_t stream)
+GF_API int gf_fisheye_maps_16sc2(void* ctx, const double D[4], const gf_frame_xform* xf, int w, int h, int16_t* map1, size_t s1, uint16_t* map2, size_t s2, gf_stream_t stream)
 {
-    return maps_common(ctx, xf, w, h, map1, s1, map2, s2, true, stream);
+    return maps_common(ctx, D, xf, w, h, map1, s1, map2, s2, true, stream);
 }
 
-GF_API int gf_fisheye_maps_32f(void* ctx, const gf_frame_xform* xf, int w, int h, float* mx, size_t sx, float* my, size_t sy, gf_stream_t stream)
+GF_API int gf_fisheye_maps_32f(void* ctx, const double D[4], const gf_frame_xform* xf, int w, int h, float* mx, size_t sx, float* my, size_t sy, gf_stream_t stream)
 {
-    return maps_common(ctx, xf, w, h, mx, sx, my, sy, false, stream);
+    return maps_common(ctx, D, xf, w, h, mx, sx, my, sy, false, stream);
 }
 
 GF_API int gf_convert_maps_32f_16sc2(void* ctx, const float* mx, size_t mxs, const float* my, size_t mys,
@@ -722,9 +1023,10 @@ GF_API int gf_convert_maps_32f_16sc2(void* ctx, const float* mx, size_t mxs, con
         return fail(GF_ERR_INVALID_ARG, "%s: step/alignment invalid (w=%lld)", "gf_convert_maps_32f_16sc2", w);
     if (sxd == 0.f || syd == 0.f) return fail(GF_ERR_INVALID_ARG, "%s: zero scale denominator", "gf_convert_maps_32f_16sc2");
     const int scale_on = !(sxn == 1.f && sxd == 1.f && syn == 1.f && syd == 1.f);
+    DeviceGuard dg(((Ctx*)ctx)->device);
     dim3 grid((w + 63)/64, (h + 3)/4);
-    hipLaunchKernelGGL(k_convert_maps, grid, dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)mx, (long)mxs, (const uint8_t*)my, (long)mys,
-                       sxn, sxd, syn, syd, scale_on, w, h, (uint8_t*)map1, (long)s1, (uint8_t*)map2, (long)s2);
+    hipLaunchKernelGGL(k_convert_maps, grid, dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)mx, mxs, (const uint8_t*)my, mys,
+                       sxn, sxd, syn, syd, scale_on, w, h, (uint8_t*)map1, s1, (uint8_t*)map2, s2);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
@@ -742,9 +1044,10 @@ GF_API int gf_remap_linear_c3(void* ctx, int depth, const void* src, int sw, int
     if (s1 < (size_t)dw*4 || s2 < (size_t)dw*2 || (s1 & 1) || (s2 & 1) || ((uintptr_t)map1 & 1) || ((uintptr_t)map2 & 1))
         return fail(GF_ERR_INVALID_ARG, "%s: map step/alignment invalid (step1=%lld)", "gf_remap_linear_c3", (long long)s1);
     if (ranges_overlap(src, sstep*sh, dst, dstep*dh)) return fail(GF_ERR_INVALID_ARG, "%s: src and dst overlap", "gf_remap_linear_c3");
+    DeviceGuard dg(((Ctx*)ctx)->device);
     RemapArgs A = make_args(depth, src, sw, sh, sstep, 0, dst, dw, dh, dstep, 0, bv);
     dim3 grid(A.tiles_x*A.tiles_y, 1);
-    DISPATCH_DEPTH_BORDER(k_remap_linear, depth, border, grid, (hipStream_t)stream, A, (const uint8_t*)map1, (long)s1, (const uint8_t*)map2, (long)s2);
+    DISPATCH_DEPTH_BORDER(k_remap_linear, depth, border, grid, (hipStream_t)stream, A, (const uint8_t*)map1, s1, (const uint8_t*)map2, s2);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
@@ -763,9 +1066,10 @@ GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, in
         return fail(GF_ERR_INVALID_ARG, "%s: map step/alignment invalid (w=%lld)", "gf_remap_cubic_u8c3_f32maps", dw);
     if (ranges_overlap(src, sstep*sh, dst, dstep*dh)) return fail(GF_ERR_INVALID_ARG, "%s: src and dst overlap", "gf_remap_cubic_u8c3_f32maps");
     int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
+    DeviceGuard dg(((Ctx*)ctx)->device);
     dim3 grid((dw + 63)/64, (dh + 3)/4);
-    hipLaunchKernelGGL(k_remap_cubic_u8c3, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, (long)sstep, dst, dw, dh, (long)dstep,
-                       (const uint8_t*)mx, (long)mxs, (const uint8_t*)my, (long)mys, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
+    hipLaunchKernelGGL(k_remap_cubic_u8c3, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, dst, dw, dh, dstep,
+                       (const uint8_t*)mx, mxs, (const uint8_t*)my, mys, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
@@ -790,20 +1094,24 @@ static int fused_checks(const char* fn, void* ctx, int depth, const void* src, i
 
 GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                            void* dst, int dw, int dh, size_t dstep, size_t dframe,
-                           const gf_frame_xform* xf_dev, int n_frames, int border, const double bv[4], gf_stream_t stream)
+                           const double D[4], const gf_frame_xform* xf_dev, int n_frames, int border, const double bv[4], gf_stream_t stream)
 {
     int rc = fused_checks("gf_undistort_rotate_c3", ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_frames, n_frames, border);
     if (rc) return rc;
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    const double* lens; LensK lk;
+    rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
     dim3 grid(A.tiles_x*A.tiles_y, n_frames);
-    DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev);
+    DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
 
 GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                                  void* dst, int dw, int dh, size_t dstep, size_t dframe,
-                                 const gf_frame_xform* xf_dev, int n_out, int frames_per_group, int n_blend,
+                                 const double D[4], const gf_frame_xform* xf_dev, int n_out, int frames_per_group, int n_blend,
                                  int border, const double bv[4], gf_stream_t stream)
 {
     if (n_blend < 1 || frames_per_group < n_blend) return fail(GF_ERR_INVALID_ARG, "%s: need 1 <= n_blend <= frames_per_group (n_blend=%lld)", "gf_undistort_rotate_blend_c3", n_blend);
@@ -811,14 +1119,18 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
     const long long n_in = (long long)(n_out - 1)*frames_per_group + n_blend;
     int rc = fused_checks("gf_undistort_rotate_blend_c3", ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_in, n_out, border);
     if (rc) return rc;
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    const double* lens; LensK lk;
+    rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
     dim3 grid(A.tiles_x*A.tiles_y, n_out);
     if (depth == GF_DEPTH_U8) {
-        if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, frames_per_group, n_blend);
-        else                              hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_REPLICATE>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, frames_per_group, n_blend);
+        if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
+        else                              hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_REPLICATE>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
     } else {
-        if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U16, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, frames_per_group, n_blend);
-        else                              hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U16, GF_BORDER_REPLICATE>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, frames_per_group, n_blend);
+        if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U16, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
+        else                              hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U16, GF_BORDER_REPLICATE>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
     }
     HIP_TRY(hipGetLastError());
     return GF_OK;
@@ -830,6 +1142,7 @@ GF_API int gf_blend_accumulate(void* ctx, int depth, const void* frame, double* 
     if (depth != GF_DEPTH_U8 && depth != GF_DEPTH_U16) return fail(GF_ERR_UNSUPPORTED, "depth %s%lld not supported", "", depth);
     if (!frame || !acc || n == 0) return fail(GF_ERR_INVALID_ARG, "%s: null pointer or n == 0", "gf_blend_accumulate");
     if (((uintptr_t)acc & 7) || (depth == GF_DEPTH_U16 && ((uintptr_t)frame & 1))) return fail(GF_ERR_INVALID_ARG, "%s: misaligned buffer", "gf_blend_accumulate");
+    DeviceGuard dg(((Ctx*)ctx)->device);
     const unsigned blocks = (unsigned)((n + BLOCK - 1)/BLOCK < 8192 ? (n + BLOCK - 1)/BLOCK : 8192);
     if (depth == GF_DEPTH_U8) hipLaunchKernelGGL(k_blend_acc<uint8_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)frame, acc, weight, reset, n);
     else                      hipLaunchKernelGGL(k_blend_acc<uint16_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint16_t*)frame, acc, weight, reset, n);
@@ -843,6 +1156,7 @@ GF_API int gf_blend_finalize(void* ctx, int depth, const double* acc, void* out,
     if (depth != GF_DEPTH_U8 && depth != GF_DEPTH_U16) return fail(GF_ERR_UNSUPPORTED, "depth %s%lld not supported", "", depth);
     if (!acc || !out || n == 0) return fail(GF_ERR_INVALID_ARG, "%s: null pointer or n == 0", "gf_blend_finalize");
     if (((uintptr_t)acc & 7) || (depth == GF_DEPTH_U16 && ((uintptr_t)out & 1))) return fail(GF_ERR_INVALID_ARG, "%s: misaligned buffer", "gf_blend_finalize");
+    DeviceGuard dg(((Ctx*)ctx)->device);
     const unsigned blocks = (unsigned)((n + BLOCK - 1)/BLOCK < 8192 ? (n + BLOCK - 1)/BLOCK : 8192);
     if (depth == GF_DEPTH_U8) hipLaunchKernelGGL(k_blend_fin<uint8_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, acc, (uint8_t*)out, n);
     else                      hipLaunchKernelGGL(k_blend_fin<uint16_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, acc, (uint16_t*)out, n);

@@ -74,17 +74,18 @@ def fisheye_initUndistortRectifyMap(K, D, R, P, size, m1type, device=None):
     m1type CV_16SC2 -> int16[H,W,2] + uint16[H,W];  CV_32FC1 -> float32[H,W] x 2."""
     dev = _device(device)
     w, h = int(size[0]), int(size[1])
-    xf = _lib.make_frame_xform(K, D, R, P)
+    xf = _lib.make_frame_xform(K, R, P)
+    Dk = _lib.distortion(D)
     lib, ctx = _lib.load(), _lib.ctx(dev.index)
     with torch.cuda.device(dev):
         if m1type == CV_16SC2:
             m1 = torch.empty((h, w, 2), dtype=torch.int16, device=dev)
             m2 = torch.empty((h, w), dtype=torch.uint16, device=dev)
-            _lib.check(lib.gf_fisheye_maps_16sc2(ctx, C.byref(xf), w, h, _ptr(m1), w * 4, _ptr(m2), w * 2, _stream(dev)))
+            _lib.check(lib.gf_fisheye_maps_16sc2(ctx, Dk, C.byref(xf), w, h, _ptr(m1), w * 4, _ptr(m2), w * 2, _stream(dev)))
         elif m1type == CV_32FC1:
             m1 = torch.empty((h, w), dtype=torch.float32, device=dev)
             m2 = torch.empty((h, w), dtype=torch.float32, device=dev)
-            _lib.check(lib.gf_fisheye_maps_32f(ctx, C.byref(xf), w, h, _ptr(m1), w * 4, _ptr(m2), w * 4, _stream(dev)))
+            _lib.check(lib.gf_fisheye_maps_32f(ctx, Dk, C.byref(xf), w, h, _ptr(m1), w * 4, _ptr(m2), w * 4, _stream(dev)))
         else:
             raise ValueError("m1type must be CV_16SC2 or CV_32FC1")
     return m1, m2
@@ -180,7 +181,7 @@ def remap(src, map1, map2, interpolation, dst=None, borderMode=BORDER_CONSTANT, 
 
 
 def xforms_to_device(xforms, device=None):
-    """[N,17] float64 numpy (rows = gf_frame_xform) -> CUDA tensor for undistort_rotate()."""
+    """[N,13] float64 numpy (rows = gf_frame_xform) -> CUDA tensor for undistort_rotate()."""
     dev = _device(device)
     a = np.ascontiguousarray(np.asarray(xforms, np.float64).reshape(-1, _lib.XFORM_DOUBLES))
     return torch.from_numpy(a).to(dev)
@@ -194,18 +195,18 @@ def _frames4(t, what):
     return t
 
 
-def undistort_rotate(src, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
     """Fused get_maps + remap(INTER_LINEAR) for a batch of frames (stabilizer.py:1423-1443 per frame).
 
     src: CUDA uint8/uint16 [N,H,W,3] (or [H,W,3]; a stride-0 expand() over N reuses one input frame).
-    xforms_dev: CUDA float64 [N,17] from xforms_to_device().  Returns dst [N,out_h,out_w,3]."""
+    D: the lens's distortion coefficients k1..k4 (host).  xforms_dev: CUDA float64 [N,13] from xforms_to_device().  Returns dst [N,out_h,out_w,3]."""
     if not (isinstance(src, torch.Tensor) and src.is_cuda):
         raise TypeError("undistort_rotate works on CUDA tensors")
     dev = src.device
     s = _frames4(src, "src")
     n = s.shape[0]
     if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
-        raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,17] tensor with N = number of frames")
+        raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,13] tensor with N = number of frames")
     dw, dh = int(out_size[0]), int(out_size[1])
     if dst is None:
         d = torch.zeros((n, dh, dw, 3), dtype=s.dtype, device=dev) if borderMode == BORDER_TRANSPARENT else \
@@ -218,12 +219,12 @@ def undistort_rotate(src, xforms_dev, out_size, dst=None, borderMode=BORDER_CONS
     lib, ctx = _lib.load(), _lib.ctx(dev.index)
     with torch.cuda.device(dev):
         _lib.check(lib.gf_undistort_rotate_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
-                                              _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _ptr(xforms_dev), n,
-                                              int(borderMode), _lib.border_value(borderValue), _stream(dev)))
+                                              _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _lib.distortion(D),
+                                              _ptr(xforms_dev), n, int(borderMode), _lib.border_value(borderValue), _stream(dev)))
     return d if (dst is None or dst.dim() == 4) else d[0]
 
 
-def undistort_rotate_blend(src, xforms_dev, out_size, frames_per_group, n_blend, dst=None,
+def undistort_rotate_blend(src, D, xforms_dev, out_size, frames_per_group, n_blend, dst=None,
                            borderMode=BORDER_CONSTANT, borderValue=0):
     """Fused remap + hyperlapse blend (stabilizer.py:1431-1447,1464-1468): output g is the truncated float64 mean of
     the remaps of input frames g*frames_per_group .. +n_blend-1.  src [N_in,H,W,3], returns [n_out,out_h,out_w,3]."""
@@ -245,8 +246,8 @@ def undistort_rotate_blend(src, xforms_dev, out_size, frames_per_group, n_blend,
     lib, ctx = _lib.load(), _lib.ctx(dev.index)
     with torch.cuda.device(dev):
         _lib.check(lib.gf_undistort_rotate_blend_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
-                                                    _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _ptr(xforms_dev),
-                                                    n_out, int(frames_per_group), int(n_blend), int(borderMode),
+                                                    _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _lib.distortion(D),
+                                                    _ptr(xforms_dev), n_out, int(frames_per_group), int(n_blend), int(borderMode),
                                                     _lib.border_value(borderValue), _stream(dev)))
     return d
 

@@ -249,9 +249,9 @@ class Stabilizer:
 
             def launch(din, dout):
                 if nblend == 1:
-                    cv.undistort_rotate(din, xf_dev, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue)
+                    cv.undistort_rotate(din, self.undistort.D, xf_dev, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue)
                 else:
-                    cv.undistort_rotate_blend(din, xf_dev, out_size, nblend, nblend, dst=dout[:n_groups],
+                    cv.undistort_rotate_blend(din, self.undistort.D, xf_dev, out_size, nblend, nblend, dst=dout[:n_groups],
                                               borderMode=borderMode, borderValue=borderValue)
                 return n_groups
             pipe.submit(frames, launch)

@@ -61,28 +61,31 @@ GF_API int gf_ctx_create(int device, void** ctx);
 GF_API int gf_ctx_destroy(void* ctx);
 
 /* Per-frame transform consumed by the kernels: everything cv2.fisheye.initUndistortRectifyMap derives
- * from (K, D, R, P) before its pixel loop.  iR = (P[:, :3] * R)^-1, f/c = focal/centre of K, k = D. */
+ * from (K, R, P) before its pixel loop: iR = (P[:, :3] * R)^-1, f/c = focal length/centre of K.  The lens distortion
+ * coefficients D = (k1..k4) belong to the lens, not the frame: the calls below take them as 4 HOST doubles and keep a
+ * per-context table of the radial scale function theta_d(atan r)/r for each distinct D (up to 4 lenses cached; the
+ * first call with a new D builds the 24 KB table on the host, uploads it on the call's stream and waits for that
+ * upload -- every later call is asynchronous). */
 typedef struct gf_frame_xform {
     double iR[9];
     double f[2];
     double c[2];
-    double k[4];
 } gf_frame_xform;
 
 /* HOST helper (no GPU work).  Builds one gf_frame_xform from the four matrices the reference hands to
- * cv2.fisheye.initUndistortRectifyMap at calibrate_video.py:376/383 (K=scaled_K, D, R, P=new_K), all
+ * cv2.fisheye.initUndistortRectifyMap at calibrate_video.py:376/383 (K=scaled_K, R, P=new_K), all
  * row-major host doubles.  GF_ERR_SINGULAR if P*R is not invertible. */
-GF_API int gf_make_frame_xform(const double K_host[9], const double D_host[4], const double R_host[9],
-                        const double P_host[9], gf_frame_xform* out_host);
+GF_API int gf_make_frame_xform(const double K_host[9], const double R_host[9], const double P_host[9],
+                        gf_frame_xform* out_host);
 
 /* cv2.fisheye.initUndistortRectifyMap(K, D, R, P, (out_w,out_h), cv2.CV_16SC2)
  *   replaces calibrate_video.py:383 (and :322 with R = I).  map1: int16 [out_h][out_w][2],
  *   map2: uint16 [out_h][out_w] = (fy<<5)|fx, INTER_BITS = 5.  xf is a HOST pointer. */
-GF_API int gf_fisheye_maps_16sc2(void* ctx, const gf_frame_xform* xf_host, int out_w, int out_h,
+GF_API int gf_fisheye_maps_16sc2(void* ctx, const double D_host[4], const gf_frame_xform* xf_host, int out_w, int out_h,
                           int16_t* map1, size_t map1_step, uint16_t* map2, size_t map2_step, gf_stream_t stream);
 
 /* cv2.fisheye.initUndistortRectifyMap(..., cv2.CV_32FC1) -- calibrate_video.py:376 (stretched presets). */
-GF_API int gf_fisheye_maps_32f(void* ctx, const gf_frame_xform* xf_host, int out_w, int out_h,
+GF_API int gf_fisheye_maps_32f(void* ctx, const double D_host[4], const gf_frame_xform* xf_host, int out_w, int out_h,
                         float* mapx, size_t mapx_step, float* mapy, size_t mapy_step, gf_stream_t stream);
 
 /* cv2.convertMaps(mapx * sx_num / sx_den, mapy * sy_num / sy_den, cv2.CV_16SC2) -- calibrate_video.py:378.
@@ -117,7 +120,7 @@ GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, in
  * Output is bit-identical to gf_fisheye_maps_16sc2 followed by gf_remap_linear_c3. */
 GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
                            void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
-                           const gf_frame_xform* xf_dev, int n_frames,
+                           const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
                            int border, const double border_value_host[4], gf_stream_t stream);
 
 /* Hyperlapse blend, replaces the numpy float64 passes at stabilizer.py:1434 (reset), :1447 (accumulate)
@@ -132,8 +135,13 @@ GF_API int gf_blend_finalize(void* ctx, int depth, const double* acc, void* out,
  * src holds n_out*... input frames: input frame index for (g,b) is g*frames_per_group + b. */
 GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
                                  void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
-                                 const gf_frame_xform* xf_dev, int n_out, int frames_per_group, int n_blend,
+                                 const double D_host[4], const gf_frame_xform* xf_dev, int n_out, int frames_per_group, int n_blend,
                                  int border, const double border_value_host[4], gf_stream_t stream);
+
+/* HOST (no GPU work): the kernels' table approximation of the radial scale S(t) = theta_d(atan sqrt t)/sqrt t of
+ * cv::fisheye::initUndistortRectifyMap, evaluated exactly as on the device, for n values t = x^2 + y^2 in [0, 255)
+ * (NaN outside: there the kernels use the exact formula).  Lets CPU tests bound the table's error. */
+GF_API int gf_lens_scale_host(const double D_host[4], const double* t_host, size_t n, double* out_host);
 
 /* HOST: copy out the 1024x16 int16 bicubic weight table the library uses (tests compare it with the oracle's). */
 GF_API int gf_get_cubic_table(int16_t* out_host);

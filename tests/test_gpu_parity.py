@@ -141,13 +141,13 @@ def test_fused_equals_maps_plus_remap(gpu, orc, golden_calls, dtype, border):
     for i in range(3):
         Ri = Rotation.from_euler("zyx", [3 * i, 2 - 4 * i, 1.5 * i], degrees=True).as_matrix() @ Rb
         Rs.append(Ri)
-        xfs.append(_lib.xform_to_array(_lib.make_frame_xform(Ks, D, Ri, Ps)))
+        xfs.append(_lib.xform_to_array(_lib.make_frame_xform(Ks, Ri, Ps)))
     xf_dev = cv.xforms_to_device(np.stack(xfs), gpu)
     src = torch.from_numpy(frames).to(gpu)
     prev = np.stack([_rand_img(rng, dh, dw, dtype) for _ in range(3)])
     dst = torch.from_numpy(prev.copy()).to(gpu)
     bv = (10, 20, 30)
-    fused = cv.undistort_rotate(src, xf_dev, (dw, dh), dst=dst, borderMode=border, borderValue=bv).cpu().numpy()
+    fused = cv.undistort_rotate(src, D, xf_dev, (dw, dh), dst=dst, borderMode=border, borderValue=bv).cpu().numpy()
     for i in range(3):
         g1, g2 = cv.fisheye_initUndistortRectifyMap(Ks, D, Rs[i], Ps, (dw, dh), cv.CV_16SC2, device=gpu)
         two = cv.remap(src[i], g1, g2, cv.INTER_LINEAR, dst=torch.from_numpy(prev[i].copy()).to(gpu), borderMode=border,
@@ -168,8 +168,8 @@ def test_fused_full_size_4k_vs_oracle(gpu, orc, golden_calls):
     frame = synthetic_frames(3840, 2160, n=1)[0]
     o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, (3840, 2160), orc.CV_16SC2)
     want = orc.remap_linear(frame, o1, o2, nthreads=8)
-    xf = cv.xforms_to_device(_lib.xform_to_array(_lib.make_frame_xform(K, D, R, P))[None], gpu)
-    got = cv.undistort_rotate(torch.from_numpy(frame).to(gpu), xf, (3840, 2160)).cpu().numpy()
+    xf = cv.xforms_to_device(_lib.xform_to_array(_lib.make_frame_xform(K, R, P))[None], gpu)
+    got = cv.undistort_rotate(torch.from_numpy(frame).to(gpu), D, xf, (3840, 2160)).cpu().numpy()
     diff = np.abs(got.astype(np.int32) - want.astype(np.int32))
     nbad = int((diff != 0).sum())
     assert nbad <= 24, "more than a handful of pixels differ from the oracle: %d" % nbad     # rounding ties only
@@ -265,10 +265,10 @@ def test_blend_passes_and_fused_blend(gpu, orc, dtype, tdtype, n):
     from scipy.spatial.transform import Rotation
     frames = np.stack([_rand_img(rng, sh, sw, dtype) for _ in range(2 * n + 1)])
     Rs = [Rotation.from_euler("zyx", [i, -i * 0.7, 0.5 * i], degrees=True).as_matrix() for i in range(2 * n + 1)]
-    xf = np.stack([_lib.xform_to_array(_lib.make_frame_xform(K, D, R, P)) for R in Rs])
+    xf = np.stack([_lib.xform_to_array(_lib.make_frame_xform(K, R, P)) for R in Rs])
     src = torch.from_numpy(frames).to(gpu)
     xf_dev = cv.xforms_to_device(xf, gpu)
-    remapped = cv.undistort_rotate(src, xf_dev, (dw, dh), borderMode=1)
+    remapped = cv.undistort_rotate(src, D, xf_dev, (dw, dh), borderMode=1)
     # numpy reference order on the GPU-remapped frames
     want = []
     for g in range(2):
@@ -276,7 +276,7 @@ def test_blend_passes_and_fused_blend(gpu, orc, dtype, tdtype, n):
         for b in range(n):
             acc += 1 / n * remapped[g * n + b].cpu().numpy().astype(np.float64)
         want.append(acc.astype(dtype))
-    fused = cv.undistort_rotate_blend(src, xf_dev, (dw, dh), n, n, borderMode=1).cpu().numpy()
+    fused = cv.undistort_rotate_blend(src, D, xf_dev, (dw, dh), n, n, borderMode=1).cpu().numpy()
     assert fused.shape[0] == 2
     np.testing.assert_array_equal(fused, np.stack(want))
     acc = torch.full((dh, dw, 3), 5.0, dtype=torch.float64, device=gpu)
@@ -307,6 +307,6 @@ def test_error_codes(gpu):
     assert lib.gf_remap_linear_c3(ctx, 0, p(s), 8, 8, 24, p(d), 8, 8, 24, p(m1), 32, p(m2), 16, 3, bv, None) == -3   # border mode
     assert lib.gf_remap_linear_c3(ctx, 0, p(s), 40000, 8, 120000, p(d), 8, 8, 24, p(m1), 32, p(m2), 16, 0, bv, None) == -1
     with pytest.raises(_lib.GfError):
-        _lib.make_frame_xform(np.eye(3), np.zeros(4), np.zeros((3, 3)), np.eye(3))
+        _lib.make_frame_xform(np.eye(3), np.zeros((3, 3)), np.eye(3))
     with pytest.raises(TypeError):
         cv.remap(torch.zeros((4, 4, 3), dtype=torch.float32, device=gpu), m1[:4, :4], m2[:4, :4], cv.INTER_LINEAR)

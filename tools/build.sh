@@ -1,0 +1,14 @@
+#!/bin/bash
+# Builds the kernel A/B harness and ablation variants of the library into tools/_build (not product code).
+set -e
+cd "$(dirname "$0")/.."
+mkdir -p tools/_build
+F="-O3 -std=c++17 -fPIC -shared --offload-arch=gfx950 -ffp-contract=off -fvisibility=hidden"
+hipcc -O2 -std=c++17 -o tools/_build/kbench tools/kbench.cpp -ldl
+for v in "$@"; do
+  case $v in
+    nomath)   hipcc $F -DGF_ABL_NOMATH   -o tools/_build/lib_nomath.so   gyroflow_amd/csrc/gfremap.hip ;;
+    nogather) hipcc $F -DGF_ABL_NOGATHER -o tools/_build/lib_nogather.so gyroflow_amd/csrc/gfremap.hip ;;
+    both)     hipcc $F -DGF_ABL_NOMATH -DGF_ABL_NOGATHER -o tools/_build/lib_both.so gyroflow_amd/csrc/gfremap.hip ;;
+  esac
+done
