@@ -25,6 +25,7 @@
 #include <limits.h>
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <new>
 
@@ -43,14 +44,17 @@ constexpr int NXCD = 8;
 
 // lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave, degree LENS_DEG
 constexpr int LENS_OCT = 8;
-constexpr int LENS_SUB_BITS = 6;
-constexpr int LENS_N = LENS_OCT << LENS_SUB_BITS;       // 512 pieces
-constexpr int LENS_COEF = 6;                            // degree 5
-constexpr int LENS_DOUBLES = LENS_N*LENS_COEF;          // 3072 doubles = 24576 B
+constexpr int LENS_SUB_BITS = 4;
+constexpr int LENS_N = LENS_OCT << LENS_SUB_BITS;       // 128 pieces
+constexpr int LENS_COEF = 8;                            // degree 7
+constexpr int LENS_DOUBLES = LENS_N*LENS_COEF;          // 1024 doubles = 8 KB
 constexpr int LENS_SLOTS = 4;
 constexpr double ROUND_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: low dword of (x + magic) = rint(x), |x| < 2^31
 
 thread_local char g_err[512] = "";
+// A/B switch (tools/kbench): the LDS-staged variant of the fused kernel is correct but, as measured on MI355X, ~20 %
+// slower than the direct-gather kernel (more VALU work per pixel, three barriers per tile), so it is opt-in.
+const bool g_use_lds_tiles = getenv("GF_USE_LDS_TILES") != nullptr;
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0)
 {
@@ -130,9 +134,9 @@ void build_cubic_host()
 // Host: lens table.  S(t) = theta_d / r with r = sqrt(t), theta = atan r, theta_d = theta (1 + k1 theta^2 + ... +
 // k4 theta^8) is the radial scale of cv::fisheye::initUndistortRectifyMap (fisheye.cpp) as a function of
 // t = x^2 + y^2.  It is analytic in t with its nearest singularity at t = -1, so on pieces whose width is 1/64 of
-// their distance to that singularity (q = 1 + t split by binary exponent and the top 6 mantissa bits) a degree-5
-// interpolant at Chebyshev nodes is accurate to ~(1/256)^6 = 3.6e-15 relative.  Built in 80-bit long double.
-// Piece idx covers q in [2^e (1 + m/64), 2^e (1 + (m+1)/64)), e = idx >> 6, m = idx & 63; the polynomial variable is
+// their distance to that singularity (q = 1 + t split by binary exponent and the top 4 mantissa bits) a degree-7
+// interpolant at Chebyshev nodes is accurate to ~(1/64)^8 = 3.6e-15 relative.  Built in 80-bit long double.
+// Piece idx covers q in [2^e (1 + m/16), 2^e (1 + (m+1)/16)), e = idx >> 4, m = idx & 15; the polynomial variable is
 // z = (q - q_lo)/h - 0.5 in [-0.5, 0.5), which the kernel gets from q's mantissa bits without a division.
 
 long double lens_scale_ld(const double* D, long double t)
@@ -179,14 +183,14 @@ double lens_eval_host(const double* tab, double q)
 {
     uint64_t b; memcpy(&b, &q, 8);
     const int hi = (int)(b >> 32);
-    const unsigned idx = (unsigned)((hi >> 14) - (1023 << 6));
+    const unsigned idx = (unsigned)((hi >> (20 - LENS_SUB_BITS)) - (1023 << LENS_SUB_BITS));
     if (!(idx < (unsigned)LENS_N)) return NAN;
-    const uint64_t zb = ((b << 6) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    const uint64_t zb = ((b << LENS_SUB_BITS) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
     double zz; memcpy(&zz, &zb, 8);
     const double zc = zz - 1.5;
     const double* c = tab + idx*LENS_COEF;
-    double S = fma(c[5], zc, c[4]);
-    S = fma(S, zc, c[3]); S = fma(S, zc, c[2]); S = fma(S, zc, c[1]); S = fma(S, zc, c[0]);
+    double S = c[LENS_COEF - 1];
+    for (int j = LENS_COEF - 2; j >= 0; j--) S = fma(S, zc, c[j]);
     return S;
 }
 
@@ -256,8 +260,8 @@ __device__ __forceinline__ RowC row_consts(const Xf& xf, int i)
     return r;
 }
 
-// 32*u, 32*v of output pixel column j through the lens table.  Returns false (tu/tv untouched) when the pixel needs
-// the exact formula: ray behind the camera (_w <= 0), t outside [0, 255), or NaN.
+// 32*u, 32*v of output pixel column j through the lens table.  Branch-free: returns false (tu/tv then hold garbage)
+// when the pixel needs the exact formula: ray behind the camera (_w <= 0), t outside [0, 255), or NaN.
 // The column term uses one fma instead of the reference's j sequential additions (differs by < 1e-12 px).
 __device__ __forceinline__ bool coord_fast(const RowC& r, const double2* __restrict__ tab, int j, double& X, double& Y, double& W,
                                            double& tu, double& tv)
@@ -276,17 +280,19 @@ __device__ __forceinline__ bool coord_fast(const RowC& r, const double2* __restr
     const double x = X*iw, y = Y*iw;
     const double q = __fma_rn(x, x, __fma_rn(y, y, 1.0));      // 1 + t
     const int hi = __double2hiint(q);
-    const unsigned idx = (unsigned)((hi >> (20 - LENS_SUB_BITS)) - (1023 << LENS_SUB_BITS));
-    if (!(idx < (unsigned)LENS_N && W > 0)) return false;
+    const unsigned idx_raw = (unsigned)((hi >> (20 - LENS_SUB_BITS)) - (1023 << LENS_SUB_BITS));
+    const bool ok = idx_raw < (unsigned)LENS_N && W > 0;
+    const unsigned idx = min(idx_raw, (unsigned)(LENS_N - 1));  // keeps the LDS reads in bounds when !ok
     const unsigned lo = (unsigned)__double2loint(q);
     const int zhi = (int)((__builtin_amdgcn_alignbit((unsigned)hi, lo, 32 - LENS_SUB_BITS) & 0x000FFFFFu) | 0x3FF00000u);
     const double zc = __hiloint2double(zhi, (int)(lo << LENS_SUB_BITS)) - 1.5;
-    const double2 c01 = tab[idx*3], c23 = tab[idx*3 + 1], c45 = tab[idx*3 + 2];
-    double S = __fma_rn(c45.y, zc, c45.x);
-    S = __fma_rn(S, zc, c23.y); S = __fma_rn(S, zc, c23.x); S = __fma_rn(S, zc, c01.y); S = __fma_rn(S, zc, c01.x);
+    const double2 c01 = tab[idx*4], c23 = tab[idx*4 + 1], c45 = tab[idx*4 + 2], c67 = tab[idx*4 + 3];
+    double S = __fma_rn(c67.y, zc, c67.x);
+    S = __fma_rn(S, zc, c45.y); S = __fma_rn(S, zc, c45.x); S = __fma_rn(S, zc, c23.y); S = __fma_rn(S, zc, c23.x);
+    S = __fma_rn(S, zc, c01.y); S = __fma_rn(S, zc, c01.x);
     tu = __fma_rn(x*S, r.fx32, r.cx32);
     tv = __fma_rn(y*S, r.fy32, r.cy32);
-    return true;
+    return ok;
 }
 
 // Q5 integers of one pixel, fast or exact.
@@ -300,6 +306,34 @@ __device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const Lens
     } else {
         const double2 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
         iu = cv_round_d(o.x); iv = cv_round_d(o.y);
+    }
+}
+
+// Q5 integers of PXT adjacent pixels: the table path for all of them in straight-line code (independent chains
+// interleave), then the exact formula for the rare ones that need it.
+__device__ __forceinline__ void coord_q5x4(const RowC& r, const Xf& xf, const LensK& lk, const double2* __restrict__ tab, int j0,
+                                           int* iu, int* iv)
+{
+    bool ok[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        double X, Y, W, tu, tv;
+        ok[i] = coord_fast(r, tab, j0 + i, X, Y, W, tu, tv);
+        iu[i] = __double2loint(tu + ROUND_MAGIC);
+        iv[i] = __double2loint(tv + ROUND_MAGIC);
+    }
+    bool all_ok = true;
+#pragma unroll
+    for (int i = 0; i < PXT; i++) all_ok = all_ok && ok[i];
+    if (!all_ok) {
+#pragma unroll
+        for (int i = 0; i < PXT; i++)
+            if (!ok[i]) {
+                const double dj = (double)(j0 + i);
+                const double X = __fma_rn(dj, r.ax, r.rx), Y = __fma_rn(dj, r.ay, r.ry), W = __fma_rn(dj, r.aw, r.rw);
+                const double2 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
+                iu[i] = cv_round_d(o.x); iv[i] = cv_round_d(o.y);
+            }
     }
 }
 
@@ -391,16 +425,8 @@ __device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0
 // B0 G0 R0 B1 G1 R1 (bytes 0..3 and 2..5: never past the frame's last byte).  Horizontal pass with v_dot4_u32_u8 on
 // the raw dwords (weights 32-fx | fx placed on the bytes that hold the channel), vertical pass with 24-bit mads:
 // exactly sum(S * wy * wx), then (sum + 512) >> 10  ==  OpenCV's (sum(S * w_q15) + 2^14) >> 15.
-__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+__device__ __forceinline__ void bilin_u8_dot4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, int fx, int fy, int* out)
 {
-#ifdef GF_ABL_NOGATHER   /* tools/ ablation builds only: every tap hits the same cache line */
-    const unsigned off = ((sx ^ sy) & 3)*4;
-#else
-    const unsigned off = __umul24(sy, step) + __umul24(sx, 3);
-#endif
-    const uint8_t* q = base + off;
-    const uint32_t a0 = *(const u32_unaligned*)q,          a1 = *(const u32_unaligned*)(q + 2);
-    const uint32_t b0 = *(const u32_unaligned*)(q + step), b1 = *(const u32_unaligned*)(q + step + 2);
     const unsigned wx0 = 32 - fx;
     const unsigned wbr = wx0 | ((unsigned)fx << 24);            // bytes 0 and 3: B0,B1 of a0 / R0,R1 of a1
     const unsigned wg0 = wx0 << 8, wg1 = (unsigned)fx << 16;    // G0 = byte 1 of a0, G1 = byte 2 of a1
@@ -414,23 +440,60 @@ __device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ b
     out[2] = (int)((__umul24(bR, fy) + (__umul24(tR, wy0) + 512u)) >> 10);
 }
 
-// Interior pixel, u16: OpenCV's float path -- float32 weights, ((p00 w00 + p01 w01) + p10 w10) + p11 w11 with every
-// product and sum rounded (no FMA), cvRound, saturate.
-__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
 {
-#ifdef GF_ABL_NOGATHER
+#ifdef GF_ABL_NOGATHER   /* tools/ ablation builds only: every tap hits the same cache line */
     const unsigned off = ((sx ^ sy) & 3)*4;
 #else
-    const unsigned off = __umul24(sy, step) + __umul24(sx, 6);
+    const unsigned off = __umul24(sy, step) + __umul24(sx, 3);
 #endif
     const uint8_t* q = base + off;
-    U16x6 r0, r1;                                              // 12 bytes per source row: two pixels
-    __builtin_memcpy(&r0, q, 12);
-    __builtin_memcpy(&r1, q + step, 12);
+    // one unaligned 8-byte load per source row (half the texture-address work of two dword loads); it covers bytes
+    // 0..7 of which 0..5 are used.  The caller routes the frame's very last tap pair to the general path, so the two
+    // spare bytes never lie past the end of the frame.
+    typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
+    const uint64_t ta = *(const u64_unaligned*)q, tb = *(const u64_unaligned*)(q + step);
+    const uint32_t a0 = (uint32_t)ta, a1 = (uint32_t)(ta >> 16), b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 16);
+    bilin_u8_dot4(a0, a1, b0, b1, fx, fy, out);
+}
+
+// LDS-staged taps.  The workgroup's source box is held in LDS with one padded pixel per dword (u8: B G R x) or per
+// 8 bytes (u16: B G R x as halfwords), so the two taps of a source row are adjacent, aligned LDS words (unaligned LDS
+// reads are serialised by the hardware: SQ_LDS_UNALIGNED_STALL).  Pixel (sx, sy) of the frame sits at pixel index
+// sy*pitch + sx + base.
+typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
+struct LdsBox {
+    lds_u32 p;
+    int x0, y0;           // first tap position held
+    unsigned nx, ny;      // tap positions held: (sx - x0) < nx, (sy - y0) < ny  (their right/bottom neighbours are loaded too)
+    unsigned pitch;       // pixels per LDS row
+    int base;
+    bool on;
+};
+
+__device__ __forceinline__ void interp_u8_box(const LdsBox& L, int sx, int sy, int fx, int fy, int* out)
+{
+    const int idx = __mul24(sy, (int)L.pitch) + sx + L.base;
+    const uint32_t p00 = L.p[idx], p01 = L.p[idx + 1], p10 = L.p[idx + L.pitch], p11 = L.p[idx + L.pitch + 1];
+    // v_perm_b32: [B0 B1 G0 G1] and [R0 R1 0 0] of each source row, then three dot4 per row with (32-fx, fx)
+    const uint32_t tA = __builtin_amdgcn_perm(p01, p00, 0x05010400u), tB = __builtin_amdgcn_perm(p01, p00, 0x0c0c0602u);
+    const uint32_t bA = __builtin_amdgcn_perm(p11, p10, 0x05010400u), bB = __builtin_amdgcn_perm(p11, p10, 0x0c0c0602u);
+    const unsigned wlo = (32u - fx) | ((unsigned)fx << 8), whi = wlo << 16;
+    const unsigned tBv = __builtin_amdgcn_udot4(tA, wlo, 0u, false), tGv = __builtin_amdgcn_udot4(tA, whi, 0u, false), tRv = __builtin_amdgcn_udot4(tB, wlo, 0u, false);
+    const unsigned bBv = __builtin_amdgcn_udot4(bA, wlo, 0u, false), bGv = __builtin_amdgcn_udot4(bA, whi, 0u, false), bRv = __builtin_amdgcn_udot4(bB, wlo, 0u, false);
+    const unsigned wy0 = 32 - fy;
+    out[0] = (int)((__umul24(bBv, fy) + (__umul24(tBv, wy0) + 512u)) >> 10);
+    out[1] = (int)((__umul24(bGv, fy) + (__umul24(tGv, wy0) + 512u)) >> 10);
+    out[2] = (int)((__umul24(bRv, fy) + (__umul24(tRv, wy0) + 512u)) >> 10);
+}
+
+// u16 taps: OpenCV's float path -- float32 weights, ((p00 w00 + p01 w01) + p10 w10) + p11 w11 with every product and
+// sum rounded (no FMA), cvRound, saturate.  r0/r1 = the 12 bytes (two pixels) of the upper/lower source row.
+__device__ __forceinline__ void bilin_u16_vals(const unsigned* p00, const unsigned* p01, const unsigned* p10, const unsigned* p11,
+                                               int fx, int fy, int* out)
+{
     const float wy1 = fy*(1.f/32), wy0 = 1.f - wy1, wx1 = fx*(1.f/32), wx0 = 1.f - wx1;
     const float w00 = wy0*wx0, w01 = wy0*wx1, w10 = wy1*wx0, w11 = wy1*wx1;
-    const unsigned p00[3] = {r0.a & 0xffff, r0.a >> 16, r0.b & 0xffff}, p01[3] = {r0.b >> 16, r0.c & 0xffff, r0.c >> 16};
-    const unsigned p10[3] = {r1.a & 0xffff, r1.a >> 16, r1.b & 0xffff}, p11[3] = {r1.b >> 16, r1.c & 0xffff, r1.c >> 16};
 #pragma unroll
     for (int c = 0; c < 3; c++) {
         float t = __fmul_rn((float)p00[c], w00);
@@ -442,18 +505,69 @@ __device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ 
     }
 }
 
+__device__ __forceinline__ void bilin_u16_float(const U16x6& r0, const U16x6& r1, int fx, int fy, int* out)
+{
+    const unsigned p00[3] = {r0.a & 0xffff, r0.a >> 16, r0.b & 0xffff}, p01[3] = {r0.b >> 16, r0.c & 0xffff, r0.c >> 16};
+    const unsigned p10[3] = {r1.a & 0xffff, r1.a >> 16, r1.b & 0xffff}, p11[3] = {r1.b >> 16, r1.c & 0xffff, r1.c >> 16};
+    bilin_u16_vals(p00, p01, p10, p11, fx, fy, out);
+}
+
+__device__ __forceinline__ void interp_u16_box(const LdsBox& L, int sx, int sy, int fx, int fy, int* out)
+{
+    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) u2_t* lds_u2;
+    lds_u2 P = (lds_u2)L.p;
+    const int idx = __mul24(sy, (int)L.pitch) + sx + L.base;
+    const u2_t a0 = P[idx], a1 = P[idx + 1], b0 = P[idx + L.pitch], b1 = P[idx + L.pitch + 1];
+    const unsigned p00[3] = {a0.x & 0xffff, a0.x >> 16, a0.y & 0xffff}, p01[3] = {a1.x & 0xffff, a1.x >> 16, a1.y & 0xffff};
+    const unsigned p10[3] = {b0.x & 0xffff, b0.x >> 16, b0.y & 0xffff}, p11[3] = {b1.x & 0xffff, b1.x >> 16, b1.y & 0xffff};
+    bilin_u16_vals(p00, p01, p10, p11, fx, fy, out);
+}
+
+__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+{
+#ifdef GF_ABL_NOGATHER
+    const unsigned off = ((sx ^ sy) & 3)*4;
+#else
+    const unsigned off = __umul24(sy, step) + __umul24(sx, 6);
+#endif
+    const uint8_t* q = base + off;
+    U16x6 r0, r1;
+    __builtin_memcpy(&r0, q, 12);
+    __builtin_memcpy(&r1, q + step, 12);
+    bilin_u16_float(r0, r1, fx, fy, out);
+}
+
+
 // PXT pixels of one thread from their Q5 coordinates (iu, iv) = rint(32 u), rint(32 v).  The CV_16SC2 map would carry
 // (short)(iu >> 5): whenever the unwrapped value is inside the image it equals the wrapped one, so the interior test
 // runs on the unwrapped integers and only the general path applies the wrap.  Returns the keep mask.
 template <int DEPTH, int BORDER>
-__device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const int* iv, const int* cval, int (*px)[3])
+__device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const int* iv, const int* cval, int (*px)[3],
+                                           const LdsBox L = LdsBox{nullptr, 0, 0, 0, 0, 0, 0, false})
 {
-    const unsigned w1 = (unsigned)(s.w - 1), h1 = (unsigned)(s.h - 1);
+    unsigned keep = 0;
+    if (L.on) {
+        bool in_box = true;
+#pragma unroll
+        for (int i = 0; i < PXT; i++)
+            in_box = in_box && (unsigned)((iu[i] >> INTER_BITS) - L.x0) < L.nx && (unsigned)((iv[i] >> INTER_BITS) - L.y0) < L.ny;
+        if (in_box) {
+#pragma unroll
+            for (int i = 0; i < PXT; i++) {
+                if (DEPTH == GF_DEPTH_U8) interp_u8_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+                else                      interp_u16_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+            }
+            return 0;
+        }
+    }
+    // u8 taps are fetched with 8-byte loads (2 spare bytes): keeping the last source column pair (sx == w-2) out of the
+    // fast path means those spare bytes are always inside the row, never past the end of the frame.
+    const unsigned w1 = (unsigned)(s.w - 1) - ((DEPTH == GF_DEPTH_U8 && s.w > 1) ? 1u : 0u), h1 = (unsigned)(s.h - 1);
     bool all_in = true;
 #pragma unroll
     for (int i = 0; i < PXT; i++)
         all_in = all_in && (unsigned)(iu[i] >> INTER_BITS) < w1 && (unsigned)(iv[i] >> INTER_BITS) < h1;
-    unsigned keep = 0;
     if (all_in) {
 #pragma unroll
         for (int i = 0; i < PXT; i++) {
@@ -548,12 +662,123 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const X
         if (y >= A.dh) break;
         const RowC rc = row_consts(xf, y);
         int iu[PXT], iv[PXT];
-#pragma unroll
-        for (int i = 0; i < PXT; i++) coord_q5(rc, xf, lk, s_tab, x0 + i, iu[i], iv[i]);
+        coord_q5x4(rc, xf, lk, s_tab, x0, iu, iv);
         int px[PXT][3];
         const unsigned keep = remap4<DEPTH, BORDER>(s, iu, iv, A.cval, px);
         uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
         store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+    }
+}
+
+// K1-LDS: the same work with the source taps staged through LDS.  A gather straight from global memory costs the CU's
+// texture-address unit ~0.7 cycles per LANE (measured: 43 TA-busy cycles per 64-lane 8-byte load, TA busy 87 % of
+// the direct kernel's time), so the direct kernel cannot drop below ~17 us per 4K frame.  Here the workgroup
+//   1. estimates the source box of its 64 x (16*NPASS) output tile from 8 boundary samples (corners + edge midpoints,
+//      +-1 px margin, clamped to the frame),
+//   2. copies that box into LDS with aligned 16-byte loads (one lane-access per 5.3 source pixels instead of two per
+//      output pixel), repacking 3-byte pixels to one dword each on the way,
+//   3. gathers the taps with aligned ds_read2_b32.
+// A pixel whose taps fall outside the box (the estimate is not a bound) takes the direct path, so results never depend
+// on the estimate.  Needs a 16-byte aligned frame base and row pitch (host-checked); a box that does not fit
+// LDS_SRC_BYTES (strong zoom-out or rotation) turns the whole workgroup to the direct path.
+constexpr int LT_W = 64;
+constexpr int LT_TPR = LT_W/PXT;                 // 16 threads per output row
+constexpr int LT_RPP = BLOCK/LT_TPR;             // 16 rows per pass
+constexpr int LDS_SRC_BYTES = 31232;             // 8 KB lens table + 30.5 KB source box = 4 workgroups per CU
+
+template <int DEPTH, int BORDER, int NPASS>
+__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk)
+{
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
+    __shared__ uint4 s_src[LDS_SRC_BYTES/16];
+    __shared__ int s_box[4];                         // min sx, max sx, min sy, max sy of the boundary samples
+    constexpr int PB = DEPTH == GF_DEPTH_U8 ? 3 : 6;           // source bytes per pixel
+    constexpr int LPB = DEPTH == GF_DEPTH_U8 ? 4 : 8;          // LDS bytes per pixel
+    constexpr int LT_H = LT_RPP*NPASS;
+    const int tid = threadIdx.x;
+    if (tid < 4) s_box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+    load_lens_table(lens, s_tab);                    // ends with __syncthreads()
+    int tx, ty;
+    tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
+    const int frame = blockIdx.y;
+    const int lx = tid & (LT_TPR - 1), ly = tid / LT_TPR;
+    const int x0 = tx*LT_W + lx*PXT;
+    const Xf& xf = xfs[frame];
+    const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+
+    if (tid < 8) {                                   // boundary samples: k = 0..7 around the tile's rim
+        const int xa = tx*LT_W, xb = min(xa + LT_W - 1, A.dw - 1), ya = ty*LT_H, yb = min(ya + LT_H - 1, A.dh - 1);
+        const int k = tid < 4 ? tid : tid + 1;       // skip the centre of the 3x3 grid
+        const int kx = k % 3, ky = k / 3;
+        const int px_ = kx == 0 ? xa : kx == 1 ? (xa + xb) >> 1 : xb, py_ = ky == 0 ? ya : ky == 1 ? (ya + yb) >> 1 : yb;
+        int su, sv;
+        coord_q5(row_consts(xf, py_), xf, lk, s_tab, px_, su, sv);
+        su >>= INTER_BITS; sv >>= INTER_BITS;
+        atomicMin(&s_box[0], su); atomicMax(&s_box[1], su); atomicMin(&s_box[2], sv); atomicMax(&s_box[3], sv);
+    }
+
+    int iu[NPASS][PXT], iv[NPASS][PXT];
+#pragma unroll
+    for (int p = 0; p < NPASS; p++) {
+        const int y = ty*LT_H + p*LT_RPP + ly;
+        if (x0 < A.dw && y < A.dh) {
+            coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu[p], iv[p]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < PXT; i++) iu[p][i] = iv[p][i] = 0;
+        }
+    }
+    __syncthreads();
+
+    LdsBox L{(lds_u32)s_src, 0, 0, 0, 0, 0, 0, false};
+    {
+        // tap positions: samples +-1 px, clamped to the positions whose four taps are inside the frame
+        const int bx0 = max(s_box[0] - 1, 0), bx1 = min(s_box[1] + 1, s.w - 2);
+        const int by0 = max(s_box[2] - 1, 0), by1 = min(s_box[3] + 1, s.h - 2);
+        if (bx0 <= bx1 && by0 <= by1) {
+            const int bx0a = bx0 & ~15;                              // 16-pixel units: 48 (u8) / 96 (u16) source bytes
+            const unsigned units = (unsigned)(bx1 + 2 - bx0a + 15) >> 4, rows = (unsigned)(by1 - by0 + 2), pitch = units*16u;
+            if (rows*pitch*LPB <= (unsigned)LDS_SRC_BYTES) {
+                const size_t valid = (size_t)(s.h - 1)*s.step + (size_t)s.w*PB;      // bytes of the frame
+                for (unsigned r = (unsigned)tid >> 3; r < rows; r += BLOCK/8)
+                    for (unsigned k = (unsigned)tid & 7u; k < units; k += 8) {
+                        const size_t goff = (size_t)(by0 + (int)r)*s.step + (size_t)(bx0a + 16*(int)k)*PB;
+                        uint32_t d[PB*4];
+#pragma unroll
+                        for (int c = 0; c < PB; c++) {
+                            // aligned 16-byte chunk: if it starts inside the frame it lies in the frame's pages
+                            uint4 v = make_uint4(0, 0, 0, 0);
+                            if (goff + 16*c < valid) v = *(const uint4*)(s.base + goff + 16*c);
+                            d[4*c] = v.x; d[4*c+1] = v.y; d[4*c+2] = v.z; d[4*c+3] = v.w;
+                        }
+                        uint4* dst = s_src + ((r*pitch + 16u*k)*LPB >> 4);
+                        if (DEPTH == GF_DEPTH_U8) {
+#pragma unroll
+                            for (int m = 0; m < 4; m++)     // 4 pixels = 3 dwords -> 4 dwords (byte 3 of each is don't-care)
+                                dst[m] = make_uint4(d[3*m], __builtin_amdgcn_alignbyte(d[3*m+1], d[3*m], 3),
+                                                    __builtin_amdgcn_alignbyte(d[3*m+2], d[3*m+1], 2), d[3*m+2] >> 8);
+                        } else {
+#pragma unroll
+                            for (int m = 0; m < 8; m++)     // 2 pixels = 3 dwords -> 4 dwords
+                                dst[m] = make_uint4(d[3*m], d[3*m+1], __builtin_amdgcn_alignbit(d[3*m+2], d[3*m+1], 16), d[3*m+2] >> 16);
+                        }
+                    }
+                L.x0 = bx0; L.y0 = by0; L.nx = (unsigned)(bx1 - bx0 + 1); L.ny = (unsigned)(by1 - by0 + 1);
+                L.pitch = pitch; L.base = -(by0*(int)pitch) - bx0a; L.on = true;
+            }
+        }
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int p = 0; p < NPASS; p++) {
+        const int y = ty*LT_H + p*LT_RPP + ly;
+        if (x0 < A.dw && y < A.dh) {
+            int px[PXT][3];
+            const unsigned keep = remap4<DEPTH, BORDER>(s, iu[p], iv[p], A.cval, px, L);
+            uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+            store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+        }
     }
 }
 
@@ -585,8 +810,7 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, c
             const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
             const RowC rc = row_consts(xf, y);
             int iu[PXT], iv[PXT], o[PXT][3];
-#pragma unroll
-            for (int i = 0; i < PXT; i++) coord_q5(rc, xf, lk, s_tab, x0 + i, iu[i], iv[i]);
+            coord_q5x4(rc, xf, lk, s_tab, x0, iu, iv);
             remap4<DEPTH, BORDER>(s, iu, iv, A.cval, o);
 #pragma unroll
             for (int i = 0; i < PXT; i++)
@@ -847,6 +1071,7 @@ Xf to_xf(const gf_frame_xform* x)
 {
     Xf r;
     static_assert(sizeof(Xf) == sizeof(gf_frame_xform), "layout");
+    static_assert(LENS_COEF == 8 && LENS_DOUBLES % (2*BLOCK) == 0, "lens table layout");
     memcpy(&r, x, sizeof r);
     return r;
 }
@@ -1103,8 +1328,26 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     const double* lens; LensK lk;
     rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
-    dim3 grid(A.tiles_x*A.tiles_y, n_frames);
-    DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk);
+    const bool aligned16 = ((uintptr_t)src & 15) == 0 && (sstep & 15) == 0 && (sframe & 15) == 0;
+    if (aligned16 && g_use_lds_tiles) {               // LDS-staged source taps
+        const int npass = depth == GF_DEPTH_U8 ? 2 : 1;
+        A.tiles_x = (dw + LT_W - 1)/LT_W; A.tiles_y = (dh + LT_RPP*npass - 1)/(LT_RPP*npass);
+        dim3 grid(A.tiles_x*A.tiles_y, n_frames);
+#define LAUNCH_LDS(DEPTH_, BORDER_, NP_) hipLaunchKernelGGL((k_undistort_rotate_lds<DEPTH_, BORDER_, NP_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk)
+        if (depth == GF_DEPTH_U8) {
+            if (border == GF_BORDER_CONSTANT) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_CONSTANT, 2);
+            else if (border == GF_BORDER_REPLICATE) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_REPLICATE, 2);
+            else LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_TRANSPARENT, 2);
+        } else {
+            if (border == GF_BORDER_CONSTANT) LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_CONSTANT, 1);
+            else if (border == GF_BORDER_REPLICATE) LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_REPLICATE, 1);
+            else LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_TRANSPARENT, 1);
+        }
+#undef LAUNCH_LDS
+    } else {
+        dim3 grid(A.tiles_x*A.tiles_y, n_frames);
+        DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk);
+    }
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }

@@ -9,6 +9,9 @@ for v in "$@"; do
   case $v in
     nomath)   hipcc $F -DGF_ABL_NOMATH   -o tools/_build/lib_nomath.so   gyroflow_amd/csrc/gfremap.hip ;;
     nogather) hipcc $F -DGF_ABL_NOGATHER -o tools/_build/lib_nogather.so gyroflow_amd/csrc/gfremap.hip ;;
+    ldsaligned) hipcc $F -DGF_ABL_LDS_ALIGNED -o tools/_build/lib_ldsaligned.so gyroflow_amd/csrc/gfremap.hip ;;
+    noatomic) hipcc $F -DGF_ABL_NO_ATOMIC -o tools/_build/lib_noatomic.so gyroflow_amd/csrc/gfremap.hip ;;
+    x2) hipcc $F -DGF_EXP_X2 -o tools/_build/lib_x2.so gyroflow_amd/csrc/gfremap.hip ;;
     both)     hipcc $F -DGF_ABL_NOMATH -DGF_ABL_NOGATHER -o tools/_build/lib_both.so gyroflow_amd/csrc/gfremap.hip ;;
   esac
 done
