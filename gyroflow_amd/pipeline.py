@@ -16,7 +16,8 @@ def _np_dtype(dt):
 class BatchPipeline:
     """depth-slot ring of (pinned in, device in, device out, pinned out) batch buffers on three HIP streams.
 
-    submit(frames, launch) stages `frames` (list of HxWx3 numpy arrays, len <= batch), and enqueues
+    submit(frames, launch) stages `frames` (list of HxWx3 numpy arrays, len <= batch; or an already pinned
+    [n,H,W,3] torch tensor, e.g. a decoder's own output ring, which is uploaded without the staging copy) and enqueues
     upload -> launch(dev_in[:n], dev_out[:m]) -> download.  `launch` runs with the compute stream current and returns
     m, the number of output frames it wrote into dev_out.  Finished batches are handed, in submission order, to
     `deliver(out_frames_numpy_view)`; the view is only valid during the call."""
@@ -62,11 +63,17 @@ class BatchPipeline:
         n = len(frames)
         if n == 0 or n > self.batch:
             raise ValueError("batch of %d frames does not fit the pipeline's %d" % (n, self.batch))
-        for i, f in enumerate(frames):
-            slot["hin_np"][i] = f               # host copy into pinned memory (stands in for the decoder's output)
+        if isinstance(frames, torch.Tensor):
+            if not frames.is_pinned():
+                raise ValueError("a tensor batch must live in pinned host memory")
+            hsrc = frames
+        else:
+            for i, f in enumerate(frames):
+                slot["hin_np"][i] = f           # host copy into pinned memory (stands in for the decoder's output)
+            hsrc = slot["hin"][:n]
         with torch.cuda.device(self.dev):
             with torch.cuda.stream(self.s_h2d):
-                slot["din"][:n].copy_(slot["hin"][:n], non_blocking=True)
+                slot["din"][:n].copy_(hsrc, non_blocking=True)
                 slot["ev_h2d"].record(self.s_h2d)
             with torch.cuda.stream(self.s_comp):
                 self.s_comp.wait_event(slot["ev_h2d"])
