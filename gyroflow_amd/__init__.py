@@ -5,6 +5,7 @@ NonlinearStretch, Stabilizer.renderfile / map_function / set_hyperlapse; all pix
 (hand-written HIP, see gyroflow_amd/csrc/gfremap.hip and include/gfremap.h).  There is no CPU fallback.
 """
 from . import _lib, cv                                   # noqa: F401
+from .adaptive_zoom import AdaptiveZoom                  # noqa: F401
 from .calibrate_video import FisheyeCalibrator           # noqa: F401
 from .nonlinear_stretch import NonlinearStretch          # noqa: F401
 from .stabilizer import Stabilizer, ArraySource, ListSink, NullSink, synthetic_frames   # noqa: F401

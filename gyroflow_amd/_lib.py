@@ -48,6 +48,7 @@ SIGNATURES = {
     "gf_undistort_rotate_blend_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _i, _i, _dp, _vp],
     "gf_blend_accumulate": [_vp, _i, _vp, _vp, _d, _i, _sz, _vp],
     "gf_blend_finalize": [_vp, _i, _vp, _vp, _sz, _vp],
+    "gf_fisheye_undistort_points": [_vp, _vp, _sz, _dp, _dp, _vp, _sz, _vp, _vp],
     "gf_get_cubic_table": [_vp],
     "gf_lens_scale_host": [_dp, _dp, _sz, _dp],
 }

@@ -1002,6 +1002,50 @@ __global__ void __launch_bounds__(BLOCK) k_blend_fin(const double* __restrict__ 
         out[i] = (T)(long long)acc[i];
 }
 
+// K7: cv::fisheye::undistortPoints for n_sets rotations of one point list (AdaptiveZoom's boundary polygon,
+// adaptive_zoom.py:193-228): Newton iteration on theta (<= 10 steps, |fix| < 1e-8), scale = tan(theta)/theta_d,
+// reprojection through RR = P*R.  One thread per (set, point), all float64.
+struct PtsK { double f[2], c[2], k[4]; };
+__global__ void __launch_bounds__(BLOCK) k_undistort_points(const double* __restrict__ pts, unsigned n_pts, PtsK P,
+                                                            const double* __restrict__ RR, size_t n_total, double* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x*BLOCK + threadIdx.x;
+    if (i >= n_total) return;
+    const size_t set = i / n_pts;
+    const unsigned pi = (unsigned)(i - set*n_pts);
+    const double pwx = __ddiv_rn(pts[2*pi] - P.c[0], P.f[0]), pwy = __ddiv_rn(pts[2*pi + 1] - P.c[1], P.f[1]);
+    const double PI_2 = 1.57079632679489661923;
+    double theta_d = __dsqrt_rn(__dadd_rn(__dmul_rn(pwx, pwx), __dmul_rn(pwy, pwy)));
+    theta_d = fmin(fmax(-PI_2, theta_d), PI_2);
+    bool converged = false;
+    double theta = theta_d, scale = 1.0;
+    if (theta_d > 1e-8) {
+        for (int j = 0; j < 10; j++) {
+            const double t2 = __dmul_rn(theta, theta), t4 = __dmul_rn(t2, t2), t6 = __dmul_rn(t4, t2), t8 = __dmul_rn(t6, t2);
+            const double a = __dmul_rn(P.k[0], t2), b = __dmul_rn(P.k[1], t4), c = __dmul_rn(P.k[2], t6), d = __dmul_rn(P.k[3], t8);
+            const double num = __dsub_rn(__dmul_rn(theta, __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(1.0, a), b), c), d)), theta_d);
+            const double den = __dadd_rn(__dadd_rn(__dadd_rn(__dadd_rn(1.0, __dmul_rn(3.0, a)), __dmul_rn(5.0, b)), __dmul_rn(7.0, c)), __dmul_rn(9.0, d));
+            const double fix = __ddiv_rn(num, den);
+            theta = __dsub_rn(theta, fix);
+            if (fabs(fix) < 1e-8) { converged = true; break; }
+        }
+        scale = __ddiv_rn(tan(theta), theta_d);
+    } else {
+        converged = true;
+    }
+    const bool flipped = (theta_d < 0 && theta > 0) || (theta_d > 0 && theta < 0);
+    double ox = -1000000.0, oy = -1000000.0;
+    if (converged && !flipped) {
+        const double* R = RR + set*9;
+        const double pux = __dmul_rn(pwx, scale), puy = __dmul_rn(pwy, scale);
+        const double prx = __dadd_rn(__dadd_rn(__dmul_rn(R[0], pux), __dmul_rn(R[1], puy)), R[2]);
+        const double pry = __dadd_rn(__dadd_rn(__dmul_rn(R[3], pux), __dmul_rn(R[4], puy)), R[5]);
+        const double prz = __dadd_rn(__dadd_rn(__dmul_rn(R[6], pux), __dmul_rn(R[7], puy)), R[8]);
+        ox = __ddiv_rn(prx, prz); oy = __ddiv_rn(pry, prz);
+    }
+    out[2*i] = ox; out[2*i + 1] = oy;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host-side argument checking / launch helpers
 
@@ -1403,6 +1447,27 @@ GF_API int gf_blend_finalize(void* ctx, int depth, const double* acc, void* out,
     const unsigned blocks = (unsigned)((n + BLOCK - 1)/BLOCK < 8192 ? (n + BLOCK - 1)/BLOCK : 8192);
     if (depth == GF_DEPTH_U8) hipLaunchKernelGGL(k_blend_fin<uint8_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, acc, (uint8_t*)out, n);
     else                      hipLaunchKernelGGL(k_blend_fin<uint16_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, acc, (uint16_t*)out, n);
+    HIP_TRY(hipGetLastError());
+    return GF_OK;
+}
+
+GF_API int gf_fisheye_undistort_points(void* ctx, const double* pts, size_t n_pts, const double K_host[9], const double D_host[4],
+                                       const double* PR, size_t n_sets, double* out, gf_stream_t stream)
+{
+    if (!ctx) return fail(GF_ERR_INVALID_ARG, "%s: null ctx", "gf_fisheye_undistort_points");
+    if (!pts || !K_host || !D_host || !PR || !out) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_fisheye_undistort_points");
+    if (n_pts == 0 || n_sets == 0 || n_pts > (1u << 24) || n_sets > ((size_t)1 << 32))
+        return fail(GF_ERR_INVALID_ARG, "gf_fisheye_undistort_points: bad counts %s(n_pts=%lld)", "", (long long)n_pts);
+    if (((uintptr_t)pts | (uintptr_t)PR | (uintptr_t)out) & 7) return fail(GF_ERR_INVALID_ARG, "%s: misaligned buffer", "gf_fisheye_undistort_points");
+    PtsK P;
+    P.f[0] = K_host[0]; P.f[1] = K_host[4]; P.c[0] = K_host[2]; P.c[1] = K_host[5];
+    for (int i = 0; i < 4; i++) P.k[i] = D_host[i];
+    if (P.f[0] == 0 || P.f[1] == 0) return fail(GF_ERR_SINGULAR, "%s: zero focal length", "gf_fisheye_undistort_points");
+    DeviceGuard dg(((Ctx*)ctx)->device);
+    const size_t total = n_pts*n_sets;
+    const size_t blocks = (total + BLOCK - 1)/BLOCK;
+    if (blocks > 0x7fffffffull) return fail(GF_ERR_UNSUPPORTED, "%s: too many points", "gf_fisheye_undistort_points");
+    hipLaunchKernelGGL(k_undistort_points, dim3((unsigned)blocks), dim3(BLOCK), 0, (hipStream_t)stream, pts, (unsigned)n_pts, P, PR, total, out);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }

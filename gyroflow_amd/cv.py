@@ -4,6 +4,7 @@ Mirrors (names, argument meaning, return/ownership rules):
   cv2.fisheye.initUndistortRectifyMap   /root/reference/calibrate_video.py:322,376,383
   cv2.convertMaps                       /root/reference/calibrate_video.py:378
   cv2.remap                             /root/reference/stabilizer.py:1442, nonlinear_stretch.py:130, gyroflow.py:275,283
+  cv2.fisheye.undistortPoints           /root/reference/adaptive_zoom.py:220
 
 Arrays may be torch CUDA tensors (stay on the device, work is enqueued on torch's current stream) or numpy
 arrays (uploaded, processed on cuda:<current>, downloaded: numpy in -> numpy out, like cv2).  There is no CPU
@@ -272,6 +273,38 @@ def blend_finalize(acc, dtype):
     with torch.cuda.device(dev):
         _lib.check(lib.gf_blend_finalize(ctx, _depth(out), _ptr(acc), _ptr(out), acc.numel(), _stream(dev)))
     return out
+
+
+def fisheye_undistortPoints(distorted, K, D, R=None, P=None, device=None):
+    """cv2.fisheye.undistortPoints(distorted, K, D, R=R, P=P) (adaptive_zoom.py:220).
+
+    distorted: [1,N,2] or [N,2] float64 points.  R: None, one 3x3, or a batch [F,3,3] -- the batch form undistorts the
+    same N points under F rotations in one launch (AdaptiveZoom.compute does this for every frame).  Returns a numpy
+    array shaped like cv2's ([1,N,2] / [N,2]) for a single R, or [F,N,2] for a batch."""
+    dev = _device(device)
+    pts = np.asarray(distorted, np.float64)
+    lead = pts.shape[:-2]
+    pts2 = np.ascontiguousarray(pts.reshape(-1, 2))
+    Kc = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+    Rm = np.eye(3)[None] if R is None else np.asarray(R, np.float64).reshape(-1, 3, 3)
+    batch = R is not None and np.asarray(R).ndim == 3
+    Pm = np.eye(3) if P is None else np.asarray(P, np.float64)[:3, :3]
+    PR = np.empty((Rm.shape[0], 3, 3), np.float64)
+    for i in range(3):                       # Matx33d product, k ascending like cv::Matx (RR = PP * RR)
+        for j in range(3):
+            PR[:, i, j] = (Pm[i, 0] * Rm[:, 0, j] + Pm[i, 1] * Rm[:, 1, j]) + Pm[i, 2] * Rm[:, 2, j]
+    n_pts, n_sets = pts2.shape[0], PR.shape[0]
+    if n_pts == 0:
+        raise ValueError("no points")
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        p_d = torch.from_numpy(pts2).to(dev)
+        pr_d = torch.from_numpy(PR.reshape(-1, 9)).to(dev)
+        out = torch.empty((n_sets, n_pts, 2), dtype=torch.float64, device=dev)
+        _lib.check(lib.gf_fisheye_undistort_points(ctx, _ptr(p_d), n_pts, Kc.ctypes.data_as(_lib._dp), _lib.distortion(D),
+                                                   _ptr(pr_d), n_sets, _ptr(out), _stream(dev)))
+        res = out.cpu().numpy()
+    return res if batch else res[0].reshape(lead + (n_pts, 2))
 
 
 def cubic_table():

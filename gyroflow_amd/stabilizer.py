@@ -17,6 +17,7 @@ import torch
 from matplotlib import colors
 
 from . import cv
+from .adaptive_zoom import AdaptiveZoom
 from .calibrate_video import FisheyeCalibrator
 from .pipeline import BatchPipeline
 
@@ -131,7 +132,7 @@ class Stabilizer:
             self.device = torch.device(device)
         else:       # no GPU: only the host-side logic (schedule(), border selection) is usable
             self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
-        self.adaptive_zoom = None          # optional callable: (stab_transform, out_size, fps, smoothingFocus, tstart, tend) -> (fcorr, focalCenter)
+        self.adaptive_zoom = None          # optional override: (stab_transform, out_size, fps, smoothingFocus, tstart, tend) -> (fcorr, focalCenter)
 
     def set_hyperlapse(self, hyperlapse_multiplier=1, hyperlapse_num_blended_frames=1):
         # frames |0|1|2|3|4|5|6|7|...  mult=4, num_blend=2  ->  |0+1|4+5|...
@@ -163,12 +164,18 @@ class Stabilizer:
         return cv.BORDER_CONSTANT, [round(x * 255) for x in colors.to_rgb(bg_color)][::-1]
 
     def _fov_terms(self, out_size, smoothingFocus, tstart, tend):
+        """fcorr[n], focalCenter[n] of the reference's AdaptiveZoom.compute call (stabilizer.py:1338-1342)."""
         n = len(self.stab_transform)
         if self.adaptive_zoom is not None:
             fcorr, focal = self.adaptive_zoom(self.stab_transform, out_size, self.fps, smoothingFocus, tstart, tend)
             return np.asarray(fcorr, np.float64), np.asarray(focal, np.float64)
-        cd = self.undistort.calib_dimension
-        return np.ones(n), np.tile(np.array([cd[0] / 2, cd[1] / 2], np.float64), (n, 1))
+        if smoothingFocus == -2:       # adaptive_zoom.py:152-153 discards the polygons: all ones, crop centre = calib centre
+            cd = self.undistort.calib_dimension
+            return np.ones(n), np.tile(np.array([cd[0] / 2, cd[1] / 2], np.float64), (n, 1))
+        adaptZ = AdaptiveZoom(fisheyeCalibrator=self.undistort, device=self.device)
+        fcorr, focal = adaptZ.compute(quaternions=self.stab_transform, output_dim=out_size, fps=self.fps,
+                                      smoothingFocus=smoothingFocus, tstart=tstart, tend=tend)
+        return np.asarray(fcorr, np.float64), np.asarray(focal, np.float64)
 
     def _xform(self, fov, frame_num, out_size, focal):
         return self.undistort.frame_xform(fov, output_dim=out_size, new_img_dim=self.orig_dimension,
@@ -203,7 +210,7 @@ class Stabilizer:
             phase = k % mult
             yield frame_num, frame, phase, phase < nblend, (phase - nblend + 1) % mult == 0
 
-    def renderfile(self, starttime, stoptime, sink, out_size=(1920, 1080), fov_scale=1.0, smoothingFocus=-2,
+    def renderfile(self, starttime, stoptime, sink, out_size=(1920, 1080), fov_scale=1.0, smoothingFocus=4.0,
                    bg_color="#000000", batch=8, pipeline_depth=2, sequential=False, rank=0, world=1):
         """Render [starttime, stoptime) through the fused undistort+rotate kernel into `sink`.
 

@@ -139,6 +139,14 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
                                  const double D_host[4], const gf_frame_xform* xf_dev, int n_out, int frames_per_group, int n_blend,
                                  int border, const double border_value_host[4], gf_stream_t stream);
 
+/* cv2.fisheye.undistortPoints(pts, K, D, R=R_s, P=P) for n_sets rotations R_s of ONE list of n_pts distorted points
+ *   replaces adaptive_zoom.py:220 (AdaptiveZoom.boundingPolygon, called once per frame at adaptive_zoom.py:104).
+ * pts: DEVICE double [n_pts][2]; PR: DEVICE double [n_sets][9], row-major P*R_s (the matrix OpenCV forms before its loop;
+ * pass P when R is absent); out: DEVICE double [n_sets][n_pts][2].  Points whose Newton iteration does not converge or
+ * flips sign come back as (-1e6, -1e6), as in OpenCV 4.5.2. */
+GF_API int gf_fisheye_undistort_points(void* ctx, const double* pts, size_t n_pts, const double K_host[9], const double D_host[4],
+                                       const double* PR, size_t n_sets, double* out, gf_stream_t stream);
+
 /* HOST (no GPU work): the kernels' table approximation of the radial scale S(t) = theta_d(atan sqrt t)/sqrt t of
  * cv::fisheye::initUndistortRectifyMap, evaluated exactly as on the device, for n values t = x^2 + y^2 in [0, 255)
  * (NaN outside: there the kernels use the exact formula).  Lets CPU tests bound the table's error. */

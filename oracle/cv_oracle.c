@@ -17,6 +17,9 @@
  * restates OpenCV 4.5.2's modules/calib3d/src/fisheye.cpp and modules/imgproc/src/imgwarp.cpp
  * from their published algorithm; every behavioural quirk is isolated (Q1..Q6 below) and
  * has its own unit test in tests/test_oracle.py so it can be flipped if a real cv2 disagrees.
+ * The one exception: orc_undistort_points() is pinned (to ~1e-4, the precision the file stores) by the fcorr column
+ * and min_fcorr of the reference's plugins/blender/GX016015.MP4.gyroflow, which real cv2 produced
+ * (tests/test_oracle.py::test_undistort_points_pinned_by_gyroflow_sample).  Maps and pixels remain unpinned.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this.
  *

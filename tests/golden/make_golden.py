@@ -197,11 +197,11 @@ def gen_quats():
     st = np.array(g["stab_transform"], np.float64)      # idx, t, fcorr, w, x, y, z  (stabilizer.py:1645-1652)
     cal = g["calibration_data"]
     np.savez_compressed(os.path.join(OUT, "quats_gyroflow_sample.npz"), stab_transform=st,
-                        min_fcorr=np.array(g.get("min_fcorr", np.nan)), fps=np.array(g.get("fps", np.nan)),
+                        min_fcorr=np.array(g.get("min_fcorr", np.nan)), fps=np.array(g["video_info"]["fps"]),
                         K=np.array(cal["fisheye_params"]["camera_matrix"], np.float64),
                         D=np.array(cal["fisheye_params"]["distortion_coeffs"], np.float64),
                         calib_dimension=np.array([cal["calib_dimension"]["w"], cal["calib_dimension"]["h"]]),
-                        video_dim=np.array([g.get("video_width", 0) or 0, g.get("video_height", 0) or 0]))
+                        video_dim=np.array([g["video_info"]["orig_w"], g["video_info"]["orig_h"]]))
     print("gyroflow sample keys:", sorted(g.keys()))
 
 

@@ -89,7 +89,7 @@ def test_renderfile_matches_reference_loop(gpu, orc, mode):
     st = Stabilizer(ArraySource(frames, fail_at=fail_at), cal, stab, fps, w, h, device=gpu)
     st.set_hyperlapse(mode["mult"], mode["nblend"])
     sink = ListSink()
-    nw = st.renderfile(start, stop, sink, out_size=out_size, fov_scale=1.3, bg_color=mode["bg"],
+    nw = st.renderfile(start, stop, sink, out_size=out_size, fov_scale=1.3, smoothingFocus=-2, bg_color=mode["bg"],
                        batch=mode.get("batch", 8), sequential=mode.get("sequential", False))
     want = reference_loop(orc, cal, frames, set(fail_at), stab, fps, start, stop, out_size, 1.3, mode["bg"], mode["mult"],
                           mode["nblend"], (w, h))

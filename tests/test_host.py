@@ -219,3 +219,29 @@ def test_lens_table_accuracy():
         rel = np.abs((got.astype(np.longdouble) - want) / want)[big]
         assert float(rel.max()) < 2e-14, (D, float(rel.max()))
     assert np.isnan(_lib.lens_scale_host(Ds[1], [255.0, 1e6, np.inf, np.nan, -2.5])).all()      # outside: exact path
+
+
+def test_adaptive_zoom_host_math_matches_per_frame_restatement(orc):
+    """The batched findFcorr/findFov arithmetic (numpy, no GPU) against the per-frame restatement with scipy's interp1d,
+    on polygons produced by the oracle's undistortPoints."""
+    import ref_adaptive_zoom as raz
+    from gyroflow_amd import FisheyeCalibrator
+    from gyroflow_amd.adaptive_zoom import AdaptiveZoom
+    z = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero9_4k_43"))
+    az = AdaptiveZoom(cal)
+    q = z["stab_transform"][::25, 3:7]
+    polys = np.stack([raz.bounding_polygon(orc, cal.K, cal.D, cal.calib_dimension, qq) for qq in q])
+    centers = np.tile([2000.0, 1500.0], (len(q), 1))
+    for od in [(1920, 1080), (1080, 1920), (1440, 1080)]:
+        got = az._find_fov_batch(centers, polys, od)
+        want = np.array([raz.find_fov(c, p, od) for c, p in zip(centers, polys)])
+        np.testing.assert_allclose(got, want, rtol=1e-12, atol=0)
+        f0, i0 = az.findFcorr(centers[3], polys[3], od)
+        f1, i1 = raz.find_fcorr(centers[3], polys[3], od)
+        assert f0 == f1 and i0 == i1
+        assert az.findFov(centers[3], polys[3], od) == pytest.approx(want[3], rel=1e-12)
+    assert az.findFocalCenter((100, 3900, 50, 2950), (1920, 1080)) == (2000.0, 1500.0)
+    a = np.arange(10.0)[::-1].copy()
+    np.testing.assert_array_equal(az.min_rolling(a, 3), a[2:])

@@ -270,3 +270,19 @@ def test_oracle_vectors_regression(orc, golden_calls):
     for border in (0, 1):
         out = orc.remap_linear(frame, m1, m2, borderMode=border, borderValue=(10, 20, 30))
         np.testing.assert_array_equal(out[::9, ::11], v["remap_b%d" % border])
+
+
+def test_undistort_points_pinned_by_gyroflow_sample(orc):
+    """The one result of the reference's own that pins cv2 arithmetic on this path: the fcorr column and min_fcorr of
+    plugins/blender/GX016015.MP4.gyroflow were produced by AdaptiveZoom.compute (smoothingFocus=2.0, out_size=(1920,1080):
+    stabilizer.py:1574,1637-1640), i.e. by cv2.fisheye.undistortPoints on 32 boundary points per frame.  The file stores
+    quaternions and fcorr rounded to 5 decimals, so the reproduction can only agree to ~1e-4."""
+    import ref_adaptive_zoom as raz
+    z = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
+    st = z["stab_transform"]
+    fov, centers, _ = raz.compute(orc, z["K"], z["D"], tuple(int(v) for v in z["calib_dimension"]), st[:, 3:7], (1920, 1080),
+                                  float(z["fps"]), smoothingFocus=2.0)
+    assert fov.shape == (1622,)
+    assert np.abs(fov - st[:, 2]).max() < 1.5e-4
+    assert abs(fov.min() - float(z["min_fcorr"])) < 5e-5
+    assert np.all(centers == [2000, 1500])
