@@ -41,13 +41,17 @@ constexpr int TILE_H = 32;        // output tile height (4 passes of 8 rows)
 constexpr int PASS_H = 8;
 constexpr int BLOCK = 256;
 constexpr int NXCD = 8;
+constexpr unsigned WG_PER_CU = 5;  // persistent fused kernel: workgroups resident per CU
 
-// lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave, degree LENS_DEG
+// lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave; per piece the centre q_mid and the
+// LENS_DEG+1 coefficients of a polynomial in (q - q_mid): 8 doubles = 64 bytes
 constexpr int LENS_OCT = 8;
-constexpr int LENS_SUB_BITS = 4;
-constexpr int LENS_N = LENS_OCT << LENS_SUB_BITS;       // 128 pieces
-constexpr int LENS_COEF = 8;                            // degree 7
-constexpr int LENS_DOUBLES = LENS_N*LENS_COEF;          // 1024 doubles = 8 KB
+constexpr int LENS_SUB_BITS = 5;
+constexpr int LENS_N = LENS_OCT << LENS_SUB_BITS;       // 256 pieces
+constexpr int LENS_DEG = 6;
+constexpr int LENS_COEF = 8;                            // doubles per piece: q_mid, c0..c6
+constexpr int LENS_DOUBLES = LENS_N*LENS_COEF;          // 2048 doubles = 16 KB
+constexpr unsigned LENS_HI_LIMIT = 0x3FF00000u + ((unsigned)LENS_OCT << 20);   // high dword of 2^LENS_OCT
 constexpr int LENS_SLOTS = 4;
 constexpr double ROUND_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: low dword of (x + magic) = rint(x), |x| < 2^31
 
@@ -78,6 +82,7 @@ struct LensSlot {
 
 struct Ctx {
     int device;
+    int n_cu;             // compute units of the device (sizes the persistent grid of the fused kernel)
     int16_t* cubic_tab;   // device, 1024*16 int16 (cv2 INTER_CUBIC Q15 table)
     LensSlot lens[LENS_SLOTS];
     unsigned long long tick;
@@ -133,11 +138,12 @@ void build_cubic_host()
 // ---------------------------------------------------------------------------------------------
 // Host: lens table.  S(t) = theta_d / r with r = sqrt(t), theta = atan r, theta_d = theta (1 + k1 theta^2 + ... +
 // k4 theta^8) is the radial scale of cv::fisheye::initUndistortRectifyMap (fisheye.cpp) as a function of
-// t = x^2 + y^2.  It is analytic in t with its nearest singularity at t = -1, so on pieces whose width is 1/64 of
-// their distance to that singularity (q = 1 + t split by binary exponent and the top 4 mantissa bits) a degree-7
-// interpolant at Chebyshev nodes is accurate to ~(1/64)^8 = 3.6e-15 relative.  Built in 80-bit long double.
-// Piece idx covers q in [2^e (1 + m/16), 2^e (1 + (m+1)/16)), e = idx >> 4, m = idx & 15; the polynomial variable is
-// z = (q - q_lo)/h - 0.5 in [-0.5, 0.5), which the kernel gets from q's mantissa bits without a division.
+// t = x^2 + y^2.  It is analytic in t with its nearest singularity at t = -1 (q = 0), so on pieces whose half-width is
+// 1/64 .. 1/128 of their distance to that singularity (q = 1 + t split by binary exponent and the top 5 mantissa bits)
+// a degree-6 interpolant at Chebyshev nodes is accurate to ~2 (1/128)^7 = 3.6e-15 relative.  Built in 80-bit long double.
+// Piece (e, m) covers q in [2^e (1 + m/32), 2^e (1 + (m+1)/32)).  Its slot in the table is the 8 bits of q's high dword
+// below bit 23 (three exponent bits, five mantissa bits), so the kernel indexes with a shift and a mask; the polynomial
+// variable is q - q_mid, an exact subtraction (q_mid has 7 significant bits and q is within 2 % of it).
 
 long double lens_scale_ld(const double* D, long double t)
 {
@@ -146,51 +152,56 @@ long double lens_scale_ld(const double* D, long double t)
     return th*(1.0L + th2*((long double)D[0] + th2*((long double)D[1] + th2*((long double)D[2] + th2*(long double)D[3]))))/r;
 }
 
+inline unsigned lens_slot_of_hi(unsigned hi) { return (hi >> (20 - LENS_SUB_BITS)) & (unsigned)(LENS_N - 1); }
+
 void build_lens_table(const double* D, double* tab)
 {
-    long double zn[LENS_COEF];
-    for (int k = 0; k < LENS_COEF; k++) zn[k] = 0.5L*cosl(M_PIl*(2*k + 1)/(2.0L*LENS_COEF));
-    for (int idx = 0; idx < LENS_N; idx++) {
-        const int e = idx >> LENS_SUB_BITS, m = idx & ((1 << LENS_SUB_BITS) - 1);
-        const long double h = ldexpl(1.0L, e - LENS_SUB_BITS), qlo = ldexpl(1.0L, e) + m*h;
-        long double A[LENS_COEF][LENS_COEF + 1];
-        for (int k = 0; k < LENS_COEF; k++) {
-            long double p = 1;
-            for (int j = 0; j < LENS_COEF; j++) { A[k][j] = p; p *= zn[k]; }
-            A[k][LENS_COEF] = lens_scale_ld(D, qlo + (zn[k] + 0.5L)*h - 1.0L);
-        }
-        for (int c = 0; c < LENS_COEF; c++) {               // Gaussian elimination, partial pivoting
-            int piv = c;
-            for (int r = c + 1; r < LENS_COEF; r++) if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
-            if (piv != c) for (int j = 0; j <= LENS_COEF; j++) { long double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
-            for (int r = c + 1; r < LENS_COEF; r++) {
-                const long double f = A[r][c]/A[c][c];
-                for (int j = c; j <= LENS_COEF; j++) A[r][j] -= f*A[c][j];
+    constexpr int NC = LENS_DEG + 1;
+    long double zn[NC];
+    for (int k = 0; k < NC; k++) zn[k] = cosl(M_PIl*(2*k + 1)/(2.0L*NC));       // nodes in [-1, 1]
+    for (int e = 0; e < LENS_OCT; e++)
+        for (int m = 0; m < (1 << LENS_SUB_BITS); m++) {
+            const long double hh = ldexpl(1.0L, e - LENS_SUB_BITS - 1);             // half width (a power of two)
+            const long double qmid = ldexpl(1.0L, e) + (2*m + 1)*hh;
+            long double A[NC][NC + 1];
+            for (int k = 0; k < NC; k++) {
+                long double p = 1;
+                for (int j = 0; j < NC; j++) { A[k][j] = p; p *= zn[k]; }
+                A[k][NC] = lens_scale_ld(D, qmid + zn[k]*hh - 1.0L);
             }
+            for (int c = 0; c < NC; c++) {                   // Gaussian elimination, partial pivoting
+                int piv = c;
+                for (int r = c + 1; r < NC; r++) if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+                if (piv != c) for (int j = 0; j <= NC; j++) { long double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+                for (int r = c + 1; r < NC; r++) {
+                    const long double f = A[r][c]/A[c][c];
+                    for (int j = c; j <= NC; j++) A[r][j] -= f*A[c][j];
+                }
+            }
+            long double a[NC];
+            for (int r = NC - 1; r >= 0; r--) {
+                long double sum = A[r][NC];
+                for (int j = r + 1; j < NC; j++) sum -= A[r][j]*a[j];
+                a[r] = sum/A[r][r];
+            }
+            const double qm = (double)qmid;
+            uint64_t b; memcpy(&b, &qm, 8);
+            double* o = tab + (size_t)lens_slot_of_hi((unsigned)(b >> 32))*LENS_COEF;
+            o[0] = qm;
+            for (int j = 0; j < NC; j++) o[1 + j] = (double)ldexpl(a[j], -j*(e - LENS_SUB_BITS - 1));   // z = (q - q_mid)/hh
         }
-        long double a[LENS_COEF];
-        for (int r = LENS_COEF - 1; r >= 0; r--) {
-            long double s = A[r][LENS_COEF];
-            for (int j = r + 1; j < LENS_COEF; j++) s -= A[r][j]*a[j];
-            a[r] = s/A[r][r];
-        }
-        for (int j = 0; j < LENS_COEF; j++) tab[idx*LENS_COEF + j] = (double)a[j];
-    }
 }
 
 // the kernel's table lookup, restated for the host (gf_lens_scale_host; CPU tests check it against long double)
 double lens_eval_host(const double* tab, double q)
 {
     uint64_t b; memcpy(&b, &q, 8);
-    const int hi = (int)(b >> 32);
-    const unsigned idx = (unsigned)((hi >> (20 - LENS_SUB_BITS)) - (1023 << LENS_SUB_BITS));
-    if (!(idx < (unsigned)LENS_N)) return NAN;
-    const uint64_t zb = ((b << LENS_SUB_BITS) & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
-    double zz; memcpy(&zz, &zb, 8);
-    const double zc = zz - 1.5;
-    const double* c = tab + idx*LENS_COEF;
+    const unsigned hi = (unsigned)(b >> 32);
+    if (!(hi >= 0x3FF00000u && hi < LENS_HI_LIMIT)) return NAN;
+    const double* c = tab + (size_t)lens_slot_of_hi(hi)*LENS_COEF;
+    const double dz = q - c[0];
     double S = c[LENS_COEF - 1];
-    for (int j = LENS_COEF - 2; j >= 0; j--) S = fma(S, zc, c[j]);
+    for (int j = LENS_COEF - 2; j >= 1; j--) S = fma(S, dz, c[j]);
     return S;
 }
 
@@ -260,17 +271,18 @@ __device__ __forceinline__ RowC row_consts(const Xf& xf, int i)
     return r;
 }
 
-// 32*u, 32*v of output pixel column j through the lens table.  Branch-free: returns false (tu/tv then hold garbage)
-// when the pixel needs the exact formula: ray behind the camera (_w <= 0), t outside [0, 255), or NaN.
+// 32*u, 32*v of output pixel column j through the lens table.  Branch-free; the caller decides from W and qhi (the
+// high dword of q = 1 + t) whether the result is usable: the pixel needs the exact formula when the ray is behind the
+// camera (_w <= 0), t is outside [0, 255), or anything is NaN (lens_ok below).
 // The column term uses one fma instead of the reference's j sequential additions (differs by < 1e-12 px).
-__device__ __forceinline__ bool coord_fast(const RowC& r, const double2* __restrict__ tab, int j, double& X, double& Y, double& W,
-                                           double& tu, double& tv)
+__device__ __forceinline__ void coord_fast(const RowC& r, const double2* __restrict__ tab, int j, double& X, double& Y, double& W,
+                                           unsigned& qhi, double& tu, double& tv)
 {
     const double dj = (double)j;
 #ifdef GF_ABL_NOMATH   /* tools/ ablation builds only: a cheap 3-degree rotation instead of the lens model */
-    X = Y = W = 1.0;
+    X = Y = W = 1.0; qhi = 0x3FF00000u;
     tu = (dj*1.003 + 2.3 + 0.05*r.rw)*32.0; tv = (r.rw*0.998 - dj*0.04 + 160.7)*32.0;
-    return true;
+    return;
 #endif
     X = __fma_rn(dj, r.ax, r.rx);
     Y = __fma_rn(dj, r.ay, r.ry);
@@ -279,28 +291,29 @@ __device__ __forceinline__ bool coord_fast(const RowC& r, const double2* __restr
     iw = __fma_rn(__fma_rn(-W, iw, 1.0), iw, iw);              // one Newton step: ~2^-49
     const double x = X*iw, y = Y*iw;
     const double q = __fma_rn(x, x, __fma_rn(y, y, 1.0));      // 1 + t
-    const int hi = __double2hiint(q);
-    const unsigned idx_raw = (unsigned)((hi >> (20 - LENS_SUB_BITS)) - (1023 << LENS_SUB_BITS));
-    const bool ok = idx_raw < (unsigned)LENS_N && W > 0;
-    const unsigned idx = min(idx_raw, (unsigned)(LENS_N - 1));  // keeps the LDS reads in bounds when !ok
-    const unsigned lo = (unsigned)__double2loint(q);
-    const int zhi = (int)((__builtin_amdgcn_alignbit((unsigned)hi, lo, 32 - LENS_SUB_BITS) & 0x000FFFFFu) | 0x3FF00000u);
-    const double zc = __hiloint2double(zhi, (int)(lo << LENS_SUB_BITS)) - 1.5;
-    const double2 c01 = tab[idx*4], c23 = tab[idx*4 + 1], c45 = tab[idx*4 + 2], c67 = tab[idx*4 + 3];
-    double S = __fma_rn(c67.y, zc, c67.x);
-    S = __fma_rn(S, zc, c45.y); S = __fma_rn(S, zc, c45.x); S = __fma_rn(S, zc, c23.y); S = __fma_rn(S, zc, c23.x);
-    S = __fma_rn(S, zc, c01.y); S = __fma_rn(S, zc, c01.x);
+    qhi = (unsigned)__double2hiint(q);
+    // byte offset of the piece: 8 bits below bit 23 of the high dword, times 64 (always inside the 16 KB table)
+    const unsigned off = (qhi >> (20 - LENS_SUB_BITS - 6)) & ((unsigned)(LENS_N - 1) << 6);
+    const double2* c = (const double2*)((const char*)tab + off);
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];  // (q_mid, a0) (a1, a2) (a3, a4) (a5, a6)
+    const double dz = q - c0.x;
+    double S = __fma_rn(c3.y, dz, c3.x);
+    S = __fma_rn(S, dz, c2.y); S = __fma_rn(S, dz, c2.x); S = __fma_rn(S, dz, c1.y); S = __fma_rn(S, dz, c1.x);
+    S = __fma_rn(S, dz, c0.y);
     tu = __fma_rn(x*S, r.fx32, r.cx32);
     tv = __fma_rn(y*S, r.fy32, r.cy32);
-    return ok;
 }
+
+__device__ __forceinline__ bool lens_ok(double W, unsigned qhi) { return qhi < LENS_HI_LIMIT && W > 0; }   // q >= 1 unless NaN
 
 // Q5 integers of one pixel, fast or exact.
 __device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const LensK& lk, const double2* __restrict__ tab, int j,
                                          int& iu, int& iv)
 {
     double X, Y, W, tu, tv;
-    if (coord_fast(r, tab, j, X, Y, W, tu, tv)) {
+    unsigned qhi;
+    coord_fast(r, tab, j, X, Y, W, qhi, tu, tv);
+    if (lens_ok(W, qhi)) {
         iu = __double2loint(tu + ROUND_MAGIC);
         iv = __double2loint(tv + ROUND_MAGIC);
     } else {
@@ -310,25 +323,27 @@ __device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const Lens
 }
 
 // Q5 integers of PXT adjacent pixels: the table path for all of them in straight-line code (independent chains
-// interleave), then the exact formula for the rare ones that need it.
+// interleave), one combined validity test (W is linear in j, so its sign is decided at the two ends; the largest high
+// dword decides the range), then the exact formula for the rare pixels that need it.
 __device__ __forceinline__ void coord_q5x4(const RowC& r, const Xf& xf, const LensK& lk, const double2* __restrict__ tab, int j0,
                                            int* iu, int* iv)
 {
-    bool ok[PXT];
+    unsigned qhi[PXT];
+    double Wj[PXT];
 #pragma unroll
     for (int i = 0; i < PXT; i++) {
-        double X, Y, W, tu, tv;
-        ok[i] = coord_fast(r, tab, j0 + i, X, Y, W, tu, tv);
+        double X, Y, tu, tv;
+        coord_fast(r, tab, j0 + i, X, Y, Wj[i], qhi[i], tu, tv);
         iu[i] = __double2loint(tu + ROUND_MAGIC);
         iv[i] = __double2loint(tv + ROUND_MAGIC);
     }
-    bool all_ok = true;
-#pragma unroll
-    for (int i = 0; i < PXT; i++) all_ok = all_ok && ok[i];
+    static_assert(PXT == 4, "combined validity test is written for 4 pixels");
+    const unsigned qmax = max(max(qhi[0], qhi[1]), max(qhi[2], qhi[3]));
+    const bool all_ok = qmax < LENS_HI_LIMIT && fmin(Wj[0], Wj[PXT - 1]) > 0;
     if (!all_ok) {
 #pragma unroll
         for (int i = 0; i < PXT; i++)
-            if (!ok[i]) {
+            if (!lens_ok(Wj[i], qhi[i])) {
                 const double dj = (double)(j0 + i);
                 const double X = __fma_rn(dj, r.ax, r.rx), Y = __fma_rn(dj, r.ay, r.ry), W = __fma_rn(dj, r.aw, r.rw);
                 const double2 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
@@ -421,40 +436,41 @@ __device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0
     return Px3{out[0], out[1], out[2], 1};
 }
 
-// Interior pixel, u8: sx in [0, w-2], sy in [0, h-2].  Two unaligned dwords per source row cover the 6 bytes
-// B0 G0 R0 B1 G1 R1 (bytes 0..3 and 2..5: never past the frame's last byte).  Horizontal pass with v_dot4_u32_u8 on
-// the raw dwords (weights 32-fx | fx placed on the bytes that hold the channel), vertical pass with 24-bit mads:
-// exactly sum(S * wy * wx), then (sum + 512) >> 10  ==  OpenCV's (sum(S * w_q15) + 2^14) >> 15.
-__device__ __forceinline__ void bilin_u8_dot4(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, int fx, int fy, int* out)
+// Interior pixel, u8.  One unaligned 8-byte load per source row covers the 6 bytes B0 G0 R0 B1 G1 R1 (+2 spare).
+// Horizontal pass: v_dot4_u32_u8 of the byte windows starting at B0, G0, R0 (the row's 8 bytes shifted by 0, 8, 16 bits)
+// with one weight word (32-fx on byte 0, fx on byte 3).  Vertical pass: two 24-bit mads per channel with the weights
+// scaled by 64, so that  sum(S wy wx)*64 + 2^15  carries the 8-bit result exactly in bits 16..23:
+//   ((sum + 512) >> 10) & 255  ==  OpenCV's (sum(S * w_q15) + 2^14) >> 15   (its Q15 weights are 32 wy wx).
+// HI16 = true leaves the result in byte 2 (store_px picks it up with v_perm_b32), false shifts it down.
+template <bool HI16>
+__device__ __forceinline__ void bilin_u8_rows(uint64_t ta, uint64_t tb, unsigned iu, unsigned iv, int* out)
 {
-    const unsigned wx0 = 32 - fx;
-    const unsigned wbr = wx0 | ((unsigned)fx << 24);            // bytes 0 and 3: B0,B1 of a0 / R0,R1 of a1
-    const unsigned wg0 = wx0 << 8, wg1 = (unsigned)fx << 16;    // G0 = byte 1 of a0, G1 = byte 2 of a1
-    const unsigned tB = __builtin_amdgcn_udot4(a0, wbr, 0u, false), bB = __builtin_amdgcn_udot4(b0, wbr, 0u, false);
-    const unsigned tR = __builtin_amdgcn_udot4(a1, wbr, 0u, false), bR = __builtin_amdgcn_udot4(b1, wbr, 0u, false);
-    const unsigned tG = __builtin_amdgcn_udot4(a1, wg1, __builtin_amdgcn_udot4(a0, wg0, 0u, false), false);
-    const unsigned bG = __builtin_amdgcn_udot4(b1, wg1, __builtin_amdgcn_udot4(b0, wg0, 0u, false), false);
-    const unsigned wy0 = 32 - fy;
-    out[0] = (int)((__umul24(bB, fy) + (__umul24(tB, wy0) + 512u)) >> 10);
-    out[1] = (int)((__umul24(bG, fy) + (__umul24(tG, wy0) + 512u)) >> 10);
-    out[2] = (int)((__umul24(bR, fy) + (__umul24(tR, wy0) + 512u)) >> 10);
+    const unsigned wx = __umul24(iu & 31u, 0xFFFFFFu) + 32u;               // (32 - fx) | fx << 24
+    const unsigned wy1 = (iv << 6) & 0x7C0u, wy0 = 2048u - wy1;             // 64 fy, 64 (32 - fy)
+    const uint32_t a0 = (uint32_t)ta, a1 = (uint32_t)(ta >> 8), a2 = (uint32_t)(ta >> 16);
+    const uint32_t b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 8), b2 = (uint32_t)(tb >> 16);
+    const unsigned tB = __builtin_amdgcn_udot4(a0, wx, 0u, false), tG = __builtin_amdgcn_udot4(a1, wx, 0u, false), tR = __builtin_amdgcn_udot4(a2, wx, 0u, false);
+    const unsigned bB = __builtin_amdgcn_udot4(b0, wx, 0u, false), bG = __builtin_amdgcn_udot4(b1, wx, 0u, false), bR = __builtin_amdgcn_udot4(b2, wx, 0u, false);
+    const unsigned rB = __umul24(bB, wy1) + (__umul24(tB, wy0) + 32768u);
+    const unsigned rG = __umul24(bG, wy1) + (__umul24(tG, wy0) + 32768u);
+    const unsigned rR = __umul24(bR, wy1) + (__umul24(tR, wy0) + 32768u);
+    out[0] = (int)(HI16 ? rB : rB >> 16); out[1] = (int)(HI16 ? rG : rG >> 16); out[2] = (int)(HI16 ? rR : rR >> 16);
 }
 
-__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+// (iu, iv): non-negative Q5 coordinates with sx = iu >> 5 in [0, w-3], sy = iv >> 5 in [0, h-2].
+template <bool HI16>
+__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv, int* out)
 {
 #ifdef GF_ABL_NOGATHER   /* tools/ ablation builds only: every tap hits the same cache line */
-    const unsigned off = ((sx ^ sy) & 3)*4;
+    const unsigned off = (((iu ^ iv) >> 5) & 3)*4;
 #else
-    const unsigned off = __umul24(sy, step) + __umul24(sx, 3);
+    const unsigned off = __umul24(iv >> 5, step) + __umul24(iu >> 5, 3u);
 #endif
-    const uint8_t* q = base + off;
-    // one unaligned 8-byte load per source row (half the texture-address work of two dword loads); it covers bytes
-    // 0..7 of which 0..5 are used.  The caller routes the frame's very last tap pair to the general path, so the two
-    // spare bytes never lie past the end of the frame.
+    // The caller routes the frame's last source column pair to the general path, so the two spare bytes of each load
+    // never lie past the end of the frame.  32-bit offsets from the uniform frame base (frames are < 2 GiB).
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-    const uint64_t ta = *(const u64_unaligned*)q, tb = *(const u64_unaligned*)(q + step);
-    const uint32_t a0 = (uint32_t)ta, a1 = (uint32_t)(ta >> 16), b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 16);
-    bilin_u8_dot4(a0, a1, b0, b1, fx, fy, out);
+    const uint64_t ta = *(const u64_unaligned*)(base + off), tb = *(const u64_unaligned*)(base + (off + step));
+    bilin_u8_rows<HI16>(ta, tb, iu, iv, out);
 }
 
 // LDS-staged taps.  The workgroup's source box is held in LDS with one padded pixel per dword (u8: B G R x) or per
@@ -524,28 +540,30 @@ __device__ __forceinline__ void interp_u16_box(const LdsBox& L, int sx, int sy, 
     bilin_u16_vals(p00, p01, p10, p11, fx, fy, out);
 }
 
-__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, int sx, int sy, int fx, int fy, int* out)
+__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv, int* out)
 {
 #ifdef GF_ABL_NOGATHER
-    const unsigned off = ((sx ^ sy) & 3)*4;
+    const unsigned off = (((iu ^ iv) >> 5) & 3)*4;
 #else
-    const unsigned off = __umul24(sy, step) + __umul24(sx, 6);
+    const unsigned off = __umul24(iv >> 5, step) + __umul24(iu >> 5, 6u);
 #endif
-    const uint8_t* q = base + off;
     U16x6 r0, r1;
-    __builtin_memcpy(&r0, q, 12);
-    __builtin_memcpy(&r1, q + step, 12);
-    bilin_u16_float(r0, r1, fx, fy, out);
+    __builtin_memcpy(&r0, base + off, 12);
+    __builtin_memcpy(&r1, base + (off + step), 12);
+    bilin_u16_float(r0, r1, (int)(iu & 31u), (int)(iv & 31u), out);
 }
 
 
 // PXT pixels of one thread from their Q5 coordinates (iu, iv) = rint(32 u), rint(32 v).  The CV_16SC2 map would carry
 // (short)(iu >> 5): whenever the unwrapped value is inside the image it equals the wrapped one, so the interior test
 // runs on the unwrapped integers and only the general path applies the wrap.  Returns the keep mask.
-template <int DEPTH, int BORDER>
+// HI16 (u8 only): pixel values are returned in bits 16..23 of px (other bits undefined); store_px<DEPTH, true> expects that.
+template <int DEPTH, int BORDER, bool HI16 = false>
 __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const int* iv, const int* cval, int (*px)[3],
                                            const LdsBox L = LdsBox{nullptr, 0, 0, 0, 0, 0, 0, false})
 {
+    static_assert(PXT == 4, "interior test is written for 4 pixels");
+    static_assert(!HI16 || DEPTH == GF_DEPTH_U8, "HI16 is a u8 representation");
     unsigned keep = 0;
     if (L.on) {
         bool in_box = true;
@@ -555,24 +573,27 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
         if (in_box) {
 #pragma unroll
             for (int i = 0; i < PXT; i++) {
-                if (DEPTH == GF_DEPTH_U8) interp_u8_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
-                else                      interp_u16_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+                if (DEPTH == GF_DEPTH_U8) {
+                    interp_u8_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+                    if (HI16) { px[i][0] <<= 16; px[i][1] <<= 16; px[i][2] <<= 16; }
+                } else {
+                    interp_u16_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+                }
             }
             return 0;
         }
     }
     // u8 taps are fetched with 8-byte loads (2 spare bytes): keeping the last source column pair (sx == w-2) out of the
     // fast path means those spare bytes are always inside the row, never past the end of the frame.
+    // Interior: 0 <= sx < w1 and 0 <= sy < h1 for all four pixels, tested on the Q5 values (negative ones are huge as unsigned).
     const unsigned w1 = (unsigned)(s.w - 1) - ((DEPTH == GF_DEPTH_U8 && s.w > 1) ? 1u : 0u), h1 = (unsigned)(s.h - 1);
-    bool all_in = true;
-#pragma unroll
-    for (int i = 0; i < PXT; i++)
-        all_in = all_in && (unsigned)(iu[i] >> INTER_BITS) < w1 && (unsigned)(iv[i] >> INTER_BITS) < h1;
-    if (all_in) {
+    const unsigned umax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
+    const unsigned vmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
+    if (umax < (w1 << INTER_BITS) && vmax < (h1 << INTER_BITS)) {
 #pragma unroll
         for (int i = 0; i < PXT; i++) {
-            if (DEPTH == GF_DEPTH_U8) interp_u8_interior(s.base, s.step, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
-            else                      interp_u16_interior(s.base, s.step, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
+            if (DEPTH == GF_DEPTH_U8) interp_u8_interior<HI16>(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i], px[i]);
+            else                      interp_u16_interior(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i], px[i]);
         }
     } else {
 #pragma unroll
@@ -581,22 +602,37 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
             const int a = (iv[i] & 31)*32 + (iu[i] & 31);
             const Px3 o = bilinear_px<DEPTH, BORDER>(s, sx, sy, a, cval[0], cval[1], cval[2]);
             if (!o.ok) keep |= 1u << i;
-            px[i][0] = o.c0; px[i][1] = o.c1; px[i][2] = o.c2;
+            px[i][0] = HI16 ? o.c0 << 16 : o.c0; px[i][1] = HI16 ? o.c1 << 16 : o.c1; px[i][2] = HI16 ? o.c2 << 16 : o.c2;
         }
     }
     return keep;
 }
 
 // Store PXT pixels (3 channels each) of one thread.  `keep` bit i set = pixel i untouched.
-template <int DEPTH>
+// HI16: u8 values sit in byte 2 of each px word; four of them are packed into a dword with three v_perm_b32.
+__device__ __forceinline__ uint32_t pack4_hi16(int a, int b, int c, int d)
+{
+    const uint32_t lo = __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x0c0c0602u);     // a.b2 | b.b2 << 8
+    const uint32_t hi = __builtin_amdgcn_perm((uint32_t)d, (uint32_t)c, 0x0c0c0602u);
+    return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
+template <int DEPTH, bool HI16 = false>
 __device__ __forceinline__ void store_px(uint8_t* drow, int x0, int dw, const int (*px)[3], unsigned keep, bool vec_ok)
 {
     typedef typename PixT<DEPTH>::T T;
     if (vec_ok && keep == 0 && x0 + PXT <= dw) {
         if (DEPTH == GF_DEPTH_U8) {
-            uint32_t w0 = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
-            uint32_t w1 = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
-            uint32_t w2 = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+            uint32_t w0, w1, w2;
+            if (HI16) {
+                w0 = pack4_hi16(px[0][0], px[0][1], px[0][2], px[1][0]);
+                w1 = pack4_hi16(px[1][1], px[1][2], px[2][0], px[2][1]);
+                w2 = pack4_hi16(px[2][2], px[3][0], px[3][1], px[3][2]);
+            } else {
+                w0 = px[0][0] | (px[0][1] << 8) | (px[0][2] << 16) | (px[1][0] << 24);
+                w1 = px[1][1] | (px[1][2] << 8) | (px[2][0] << 16) | (px[2][1] << 24);
+                w2 = px[2][2] | (px[3][0] << 8) | (px[3][1] << 16) | (px[3][2] << 24);
+            }
             uint32_t* d = (uint32_t*)(drow + (size_t)x0*3);
             struct alignas(4) W3 { uint32_t a, b, c; };
             *(W3*)d = W3{w0, w1, w2};
@@ -617,7 +653,8 @@ __device__ __forceinline__ void store_px(uint8_t* drow, int x0, int dw, const in
 #pragma unroll
     for (int i = 0; i < PXT; i++)
         if (x0 + i < dw && !((keep >> i) & 1)) {
-            d[i*3+0] = (T)px[i][0]; d[i*3+1] = (T)px[i][1]; d[i*3+2] = (T)px[i][2];
+            d[i*3+0] = (T)(HI16 ? px[i][0] >> 16 : px[i][0]); d[i*3+1] = (T)(HI16 ? px[i][1] >> 16 : px[i][1]);
+            d[i*3+2] = (T)(HI16 ? px[i][2] >> 16 : px[i][2]);
         }
 }
 
@@ -642,31 +679,53 @@ struct RemapArgs {
     int dst_vec_ok;        // dst base/step/frame stride allow 4-byte (u8) / 8-byte (u16) vector stores
 };
 
-// K1: fused fisheye map + rotation + bilinear remap, batched over frames (blockIdx.y).
+// K1: fused fisheye map + rotation + bilinear remap, batched over frames.
+// Persistent workgroups: the grid is sized to the machine (a multiple of the 8 XCDs), every workgroup loads the 16 KB
+// lens table into LDS once and then walks the work list v = blockIdx.x, blockIdx.x + gridDim.x, ... with a fixed stride, so
+// it always terminates.  v enumerates (frame, padded tile id): tiles_pad = tiles rounded up to a multiple of 8 keeps
+// v % 8 == blockIdx.x % 8, i.e. a workgroup stays on its XCD's band of every frame (tile_of_block); ids past a
+// band's end are skipped.
+__device__ __forceinline__ bool tile_of_padded_id(unsigned w, int tiles_x, int tiles_y, int& tx, int& ty)
+{
+    const unsigned n = (unsigned)(tiles_x*tiles_y);
+    const unsigned q = n / NXCD, r = n % NXCD;
+    const unsigned xcd = w % NXCD, k = w / NXCD;
+    if (k >= q + (xcd < r ? 1u : 0u)) return false;
+    const unsigned t = xcd < r ? xcd*(q + 1) + k : r*(q + 1) + (xcd - r)*q + k;
+    ty = (int)(t / (unsigned)tiles_x);
+    tx = (int)(t - (unsigned)ty*(unsigned)tiles_x);
+    return true;
+}
+
 template <int DEPTH, int BORDER>
-__global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk)
+__global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                             unsigned tiles_pad, unsigned n_work)
 {
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     load_lens_table(lens, s_tab);
-    int tx, ty;
-    tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
-    const int frame = blockIdx.y;
+    constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
     const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
-    const int x0 = tx*TILE_W + lx*PXT;
-    if (x0 >= A.dw) return;
-    const Xf& xf = xfs[frame];
-    const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
 #pragma unroll 1
-    for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
-        const int y = ty*TILE_H + pass*PASS_H + ly;
-        if (y >= A.dh) break;
-        const RowC rc = row_consts(xf, y);
-        int iu[PXT], iv[PXT];
-        coord_q5x4(rc, xf, lk, s_tab, x0, iu, iv);
-        int px[PXT][3];
-        const unsigned keep = remap4<DEPTH, BORDER>(s, iu, iv, A.cval, px);
-        uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
-        store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const unsigned frame = v / tiles_pad;
+        int tx, ty;
+        if (!tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) continue;
+        const int x0 = tx*TILE_W + lx*PXT;
+        if (x0 >= A.dw) continue;
+        const Xf& xf = xfs[frame];
+        const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+#pragma unroll 1
+        for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
+            const int y = ty*TILE_H + pass*PASS_H + ly;
+            if (y >= A.dh) break;
+            const RowC rc = row_consts(xf, y);
+            int iu[PXT], iv[PXT];
+            coord_q5x4(rc, xf, lk, s_tab, x0, iu, iv);
+            int px[PXT][3];
+            const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
+            uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+            store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+        }
     }
 }
 
@@ -859,7 +918,7 @@ __global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8
     }
 }
 
-// K2: materialised maps.  One thread per output pixel and pass, 64 x 32 tiles.
+// K2: materialised maps.  One thread per output pixel and pass, 64 x 64 tiles (16 KB lens table per workgroup).
 template <bool FIXED>
 __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const double* __restrict__ lens, int w, int h,
                                                          uint8_t* map1, size_t m1step, uint8_t* map2, size_t m2step)
@@ -869,8 +928,8 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const d
     const int j = blockIdx.x*64 + (threadIdx.x & 63);
     if (j >= w) return;
 #pragma unroll 1
-    for (int pass = 0; pass < 8; pass++) {
-        const int i = blockIdx.y*32 + pass*4 + (threadIdx.x >> 6);
+    for (int pass = 0; pass < 16; pass++) {
+        const int i = blockIdx.y*64 + pass*4 + (threadIdx.x >> 6);
         if (i >= h) break;
         const RowC rc = row_consts(xf, i);
         if (FIXED) {
@@ -884,7 +943,9 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const d
         } else {
             double X, Y, W;
             double2 o;
-            if (!coord_fast(rc, s_tab, j, X, Y, W, o.x, o.y))
+            unsigned qhi;
+            coord_fast(rc, s_tab, j, X, Y, W, qhi, o.x, o.y);
+            if (!lens_ok(W, qhi))
                 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
             ((float*)(map1 + (size_t)i*m1step))[j] = (float)(o.x*(1.0/32));
             ((float*)(map2 + (size_t)i*m2step))[j] = (float)(o.y*(1.0/32));
@@ -1199,7 +1260,8 @@ GF_API int gf_ctx_create(int device, void** ctx)
     std::call_once(g_cubic_once, build_cubic_host);
     Ctx* c = new (std::nothrow) Ctx();
     if (!c) return fail(GF_ERR_HIP, "%s: out of host memory", "gf_ctx_create");
-    c->device = device; c->cubic_tab = nullptr; c->tick = 0;
+    c->device = device; c->cubic_tab = nullptr; c->tick = 0; c->n_cu = 0;
+    if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
     for (int i = 0; i < LENS_SLOTS; i++) { c->lens[i].valid = false; c->lens[i].dev = nullptr; c->lens[i].host = nullptr; c->lens[i].last_use = 0; }
     hipError_t e = hipMalloc((void**)&c->cubic_tab, sizeof g_cubic_host);
     if (e == hipSuccess) e = hipMemcpy(c->cubic_tab, g_cubic_host, sizeof g_cubic_host, hipMemcpyHostToDevice);
@@ -1263,7 +1325,7 @@ static int maps_common(void* ctx, const double* D, const gf_frame_xform* xf, int
     DeviceGuard dg(c->device);
     const double* lens; LensK lk;
     int rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
-    dim3 grid((w + 63)/64, (h + 31)/32);
+    dim3 grid((w + 63)/64, (h + 63)/64);
     if (fixed) hipLaunchKernelGGL(k_fisheye_maps<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
     else       hipLaunchKernelGGL(k_fisheye_maps<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
     HIP_TRY(hipGetLastError());
@@ -1389,8 +1451,15 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
         }
 #undef LAUNCH_LDS
     } else {
-        dim3 grid(A.tiles_x*A.tiles_y, n_frames);
-        DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk);
+        // persistent grid: WG_PER_CU workgroups per CU (what the kernel's register and LDS use allows), a multiple of 8
+        const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
+        const unsigned long long n_work = (unsigned long long)tiles_pad*(unsigned)n_frames;
+        if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many tiles in one call (%lld)", "gf_undistort_rotate_c3", (long long)n_work);
+        unsigned blocks = (unsigned)c->n_cu*WG_PER_CU & ~(unsigned)(NXCD - 1);
+        if (blocks == 0) blocks = NXCD;
+        if (blocks > n_work) blocks = (unsigned)n_work;          // n_work is a multiple of 8
+        dim3 grid(blocks, 1);
+        DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work);
     }
     HIP_TRY(hipGetLastError());
     return GF_OK;
