@@ -36,12 +36,21 @@ namespace {
 constexpr int INTER_BITS = 5;
 constexpr int INTER_TAB_SIZE = 32;
 constexpr int PXT = 4;            // pixels per thread (horizontal)
-constexpr int TILE_W = 128;       // output tile width  (32 threads x 4 px)
-constexpr int TILE_H = 32;        // output tile height (4 passes of 8 rows)
-constexpr int PASS_H = 8;
+#ifndef GF_TILE_W
+#define GF_TILE_W 128
+#endif
+#ifndef GF_TILE_H
+#define GF_TILE_H 32
+#endif
 constexpr int BLOCK = 256;
+constexpr int TILE_W = GF_TILE_W;             // output tile width  (TILE_W/4 threads x 4 px)
+constexpr int TILE_H = GF_TILE_H;             // output tile height (passes of PASS_H rows)
+constexpr int TPR = TILE_W/PXT;               // threads per tile row
+constexpr int PASS_H = BLOCK/TPR;             // rows per pass
+static_assert(TILE_W % PXT == 0 && BLOCK % TPR == 0 && TILE_H % PASS_H == 0 && (TPR & (TPR - 1)) == 0, "tile shape");
 constexpr int NXCD = 8;
-constexpr unsigned WG_PER_CU = 5;  // persistent fused kernel: workgroups resident per CU
+const unsigned WG_PER_CU_LDS = getenv("GF_WG_PER_CU_LDS") ? (unsigned)atoi(getenv("GF_WG_PER_CU_LDS")) : 3u;
+const unsigned WG_PER_CU = getenv("GF_WG_PER_CU") ? (unsigned)atoi(getenv("GF_WG_PER_CU")) : 5u;  // persistent fused kernel: workgroups resident per CU
 
 // lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave; per piece the centre q_mid and the
 // LENS_DEG+1 coefficients of a polynomial in (q - q_mid): 8 doubles = 64 bytes
@@ -436,6 +445,16 @@ __device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0
     return Px3{out[0], out[1], out[2], 1};
 }
 
+// a*b + c with a, b < 2^24, kept as its own v_mad_u32_u24: the empty asm only stops the compiler from re-associating
+// two chained mads into mul + mul + add3.  (No instruction may sit inside an asm statement here: the hazard recogniser
+// cannot see it, and gfx950 needs wait states between v_dot4 results and a dependent VALU instruction.)
+__device__ __forceinline__ unsigned umad24(unsigned a, unsigned b, unsigned c)
+{
+    unsigned d = __umul24(a, b) + c;
+    asm("" : "+v"(d));
+    return d;
+}
+
 // Interior pixel, u8.  One unaligned 8-byte load per source row covers the 6 bytes B0 G0 R0 B1 G1 R1 (+2 spare).
 // Horizontal pass: v_dot4_u32_u8 of the byte windows starting at B0, G0, R0 (the row's 8 bytes shifted by 0, 8, 16 bits)
 // with one weight word (32-fx on byte 0, fx on byte 3).  Vertical pass: two 24-bit mads per channel with the weights
@@ -451,56 +470,70 @@ __device__ __forceinline__ void bilin_u8_rows(uint64_t ta, uint64_t tb, unsigned
     const uint32_t b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 8), b2 = (uint32_t)(tb >> 16);
     const unsigned tB = __builtin_amdgcn_udot4(a0, wx, 0u, false), tG = __builtin_amdgcn_udot4(a1, wx, 0u, false), tR = __builtin_amdgcn_udot4(a2, wx, 0u, false);
     const unsigned bB = __builtin_amdgcn_udot4(b0, wx, 0u, false), bG = __builtin_amdgcn_udot4(b1, wx, 0u, false), bR = __builtin_amdgcn_udot4(b2, wx, 0u, false);
-    const unsigned rB = __umul24(bB, wy1) + (__umul24(tB, wy0) + 32768u);
-    const unsigned rG = __umul24(bG, wy1) + (__umul24(tG, wy0) + 32768u);
-    const unsigned rR = __umul24(bR, wy1) + (__umul24(tR, wy0) + 32768u);
+    const unsigned rB = umad24(bB, wy1, umad24(tB, wy0, 32768u));
+    const unsigned rG = umad24(bG, wy1, umad24(tG, wy0, 32768u));
+    const unsigned rR = umad24(bR, wy1, umad24(tR, wy0, 32768u));
     out[0] = (int)(HI16 ? rB : rB >> 16); out[1] = (int)(HI16 ? rG : rG >> 16); out[2] = (int)(HI16 ? rR : rR >> 16);
 }
 
 // (iu, iv): non-negative Q5 coordinates with sx = iu >> 5 in [0, w-3], sy = iv >> 5 in [0, h-2].
-template <bool HI16>
-__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv, int* out)
+// The caller routes the frame's last source column pair to the general path, so the two spare bytes of each 8-byte
+// load never lie past the end of the frame.  32-bit offsets from the uniform frame base (frames are < 2 GiB).
+struct TapsU8 { uint64_t a, b; };          // the 8 bytes at (sx, sy) and at (sx, sy+1)
+
+__device__ __forceinline__ TapsU8 fetch_u8_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv)
 {
 #ifdef GF_ABL_NOGATHER   /* tools/ ablation builds only: every tap hits the same cache line */
     const unsigned off = (((iu ^ iv) >> 5) & 3)*4;
 #else
     const unsigned off = __umul24(iv >> 5, step) + __umul24(iu >> 5, 3u);
 #endif
-    // The caller routes the frame's last source column pair to the general path, so the two spare bytes of each load
-    // never lie past the end of the frame.  32-bit offsets from the uniform frame base (frames are < 2 GiB).
+#ifdef GF_ABL_NOLOAD     /* tools/ ablation builds only: no tap loads at all (VALU-only floor of the kernel) */
+    const uint64_t ta = (uint64_t)off*0x9E3779B97F4A7C15ull;
+    return TapsU8{ta, ta ^ (uint64_t)step};
+#else
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
-    const uint64_t ta = *(const u64_unaligned*)(base + off), tb = *(const u64_unaligned*)(base + (off + step));
-    bilin_u8_rows<HI16>(ta, tb, iu, iv, out);
+    return TapsU8{*(const u64_unaligned*)(base + off), *(const u64_unaligned*)(base + (off + step))};
+#endif
+}
+
+template <bool HI16>
+__device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv, int* out)
+{
+    const TapsU8 t = fetch_u8_interior(base, step, iu, iv);
+    bilin_u8_rows<HI16>(t.a, t.b, iu, iv, out);
 }
 
 // LDS-staged taps.  The workgroup's source box is held in LDS with one padded pixel per dword (u8: B G R x) or per
 // 8 bytes (u16: B G R x as halfwords), so the two taps of a source row are adjacent, aligned LDS words (unaligned LDS
-// reads are serialised by the hardware: SQ_LDS_UNALIGNED_STALL).  Pixel (sx, sy) of the frame sits at pixel index
-// sy*pitch + sx + base.
+// reads are serialised by the hardware: SQ_LDS_UNALIGNED_STALL).  Positions are handled relative to the box origin in
+// Q5 units: ru = iu - X0, rv = iv - Y0; tap position (ru >> 5, rv >> 5) sits at pixel index (rv >> 5)*pitch + (ru >> 5) + xoff.
 typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
 struct LdsBox {
     lds_u32 p;
-    int x0, y0;           // first tap position held
-    unsigned nx, ny;      // tap positions held: (sx - x0) < nx, (sy - y0) < ny  (their right/bottom neighbours are loaded too)
+    unsigned X0, Y0;      // Q5 origin (first tap position held, << 5)
+    unsigned NX, NY;      // Q5 extents: tap positions with ru < NX and rv < NY are held (with their right/bottom neighbours)
     unsigned pitch;       // pixels per LDS row
-    int base;
+    unsigned xoff;        // pixel index of the first tap column within an LDS row
     bool on;
 };
 
-__device__ __forceinline__ void interp_u8_box(const LdsBox& L, int sx, int sy, int fx, int fy, int* out)
+template <bool HI16>
+__device__ __forceinline__ void interp_u8_box(const LdsBox& L, unsigned ru, unsigned rv, int* out)
 {
-    const int idx = __mul24(sy, (int)L.pitch) + sx + L.base;
+    const unsigned idx = __umul24(rv >> 5, L.pitch) + (ru >> 5) + L.xoff;
     const uint32_t p00 = L.p[idx], p01 = L.p[idx + 1], p10 = L.p[idx + L.pitch], p11 = L.p[idx + L.pitch + 1];
     // v_perm_b32: [B0 B1 G0 G1] and [R0 R1 0 0] of each source row, then three dot4 per row with (32-fx, fx)
     const uint32_t tA = __builtin_amdgcn_perm(p01, p00, 0x05010400u), tB = __builtin_amdgcn_perm(p01, p00, 0x0c0c0602u);
     const uint32_t bA = __builtin_amdgcn_perm(p11, p10, 0x05010400u), bB = __builtin_amdgcn_perm(p11, p10, 0x0c0c0602u);
-    const unsigned wlo = (32u - fx) | ((unsigned)fx << 8), whi = wlo << 16;
+    const unsigned wlo = __umul24(ru & 31u, 0xFFu) + 32u, whi = wlo << 16;     // (32 - fx) | fx << 8
+    const unsigned wy1 = (rv << 6) & 0x7C0u, wy0 = 2048u - wy1;                 // 64 fy, 64 (32 - fy): result lands in bits 16..23
     const unsigned tBv = __builtin_amdgcn_udot4(tA, wlo, 0u, false), tGv = __builtin_amdgcn_udot4(tA, whi, 0u, false), tRv = __builtin_amdgcn_udot4(tB, wlo, 0u, false);
     const unsigned bBv = __builtin_amdgcn_udot4(bA, wlo, 0u, false), bGv = __builtin_amdgcn_udot4(bA, whi, 0u, false), bRv = __builtin_amdgcn_udot4(bB, wlo, 0u, false);
-    const unsigned wy0 = 32 - fy;
-    out[0] = (int)((__umul24(bBv, fy) + (__umul24(tBv, wy0) + 512u)) >> 10);
-    out[1] = (int)((__umul24(bGv, fy) + (__umul24(tGv, wy0) + 512u)) >> 10);
-    out[2] = (int)((__umul24(bRv, fy) + (__umul24(tRv, wy0) + 512u)) >> 10);
+    const unsigned rB = umad24(bBv, wy1, umad24(tBv, wy0, 32768u));
+    const unsigned rG = umad24(bGv, wy1, umad24(tGv, wy0, 32768u));
+    const unsigned rR = umad24(bRv, wy1, umad24(tRv, wy0, 32768u));
+    out[0] = (int)(HI16 ? rB : rB >> 16); out[1] = (int)(HI16 ? rG : rG >> 16); out[2] = (int)(HI16 ? rR : rR >> 16);
 }
 
 // u16 taps: OpenCV's float path -- float32 weights, ((p00 w00 + p01 w01) + p10 w10) + p11 w11 with every product and
@@ -528,30 +561,42 @@ __device__ __forceinline__ void bilin_u16_float(const U16x6& r0, const U16x6& r1
     bilin_u16_vals(p00, p01, p10, p11, fx, fy, out);
 }
 
-__device__ __forceinline__ void interp_u16_box(const LdsBox& L, int sx, int sy, int fx, int fy, int* out)
+__device__ __forceinline__ void interp_u16_box(const LdsBox& L, unsigned ru, unsigned rv, int* out)
 {
     typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
     typedef const __attribute__((address_space(3))) u2_t* lds_u2;
     lds_u2 P = (lds_u2)L.p;
-    const int idx = __mul24(sy, (int)L.pitch) + sx + L.base;
+    const unsigned idx = __umul24(rv >> 5, L.pitch) + (ru >> 5) + L.xoff;
     const u2_t a0 = P[idx], a1 = P[idx + 1], b0 = P[idx + L.pitch], b1 = P[idx + L.pitch + 1];
     const unsigned p00[3] = {a0.x & 0xffff, a0.x >> 16, a0.y & 0xffff}, p01[3] = {a1.x & 0xffff, a1.x >> 16, a1.y & 0xffff};
     const unsigned p10[3] = {b0.x & 0xffff, b0.x >> 16, b0.y & 0xffff}, p11[3] = {b1.x & 0xffff, b1.x >> 16, b1.y & 0xffff};
-    bilin_u16_vals(p00, p01, p10, p11, fx, fy, out);
+    bilin_u16_vals(p00, p01, p10, p11, (int)(ru & 31u), (int)(rv & 31u), out);
 }
 
-__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv, int* out)
+struct TapsU16 { U16x6 a, b; };             // the 12 bytes (two pixels) at (sx, sy) and at (sx, sy+1)
+
+__device__ __forceinline__ TapsU16 fetch_u16_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv)
 {
 #ifdef GF_ABL_NOGATHER
     const unsigned off = (((iu ^ iv) >> 5) & 3)*4;
 #else
     const unsigned off = __umul24(iv >> 5, step) + __umul24(iu >> 5, 6u);
 #endif
-    U16x6 r0, r1;
-    __builtin_memcpy(&r0, base + off, 12);
-    __builtin_memcpy(&r1, base + (off + step), 12);
-    bilin_u16_float(r0, r1, (int)(iu & 31u), (int)(iv & 31u), out);
+    TapsU16 t;
+    __builtin_memcpy(&t.a, base + off, 12);
+    __builtin_memcpy(&t.b, base + (off + step), 12);
+    return t;
 }
+
+__device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv, int* out)
+{
+    const TapsU16 t = fetch_u16_interior(base, step, iu, iv);
+    bilin_u16_float(t.a, t.b, (int)(iu & 31u), (int)(iv & 31u), out);
+}
+
+template <int DEPTH> struct TapsT;
+template <> struct TapsT<GF_DEPTH_U8>  { typedef TapsU8  T; };
+template <> struct TapsT<GF_DEPTH_U16> { typedef TapsU16 T; };
 
 
 // PXT pixels of one thread from their Q5 coordinates (iu, iv) = rint(32 u), rint(32 v).  The CV_16SC2 map would carry
@@ -566,19 +611,15 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
     static_assert(!HI16 || DEPTH == GF_DEPTH_U8, "HI16 is a u8 representation");
     unsigned keep = 0;
     if (L.on) {
-        bool in_box = true;
+        unsigned ru[PXT], rv[PXT];
 #pragma unroll
-        for (int i = 0; i < PXT; i++)
-            in_box = in_box && (unsigned)((iu[i] >> INTER_BITS) - L.x0) < L.nx && (unsigned)((iv[i] >> INTER_BITS) - L.y0) < L.ny;
-        if (in_box) {
+        for (int i = 0; i < PXT; i++) { ru[i] = (unsigned)iu[i] - L.X0; rv[i] = (unsigned)iv[i] - L.Y0; }
+        const unsigned rumax = max(max(ru[0], ru[1]), max(ru[2], ru[3])), rvmax = max(max(rv[0], rv[1]), max(rv[2], rv[3]));
+        if (rumax < L.NX && rvmax < L.NY) {
 #pragma unroll
             for (int i = 0; i < PXT; i++) {
-                if (DEPTH == GF_DEPTH_U8) {
-                    interp_u8_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
-                    if (HI16) { px[i][0] <<= 16; px[i][1] <<= 16; px[i][2] <<= 16; }
-                } else {
-                    interp_u16_box(L, iu[i] >> INTER_BITS, iv[i] >> INTER_BITS, iu[i] & 31, iv[i] & 31, px[i]);
-                }
+                if constexpr (DEPTH == GF_DEPTH_U8) interp_u8_box<HI16>(L, ru[i], rv[i], px[i]);
+                else                                interp_u16_box(L, ru[i], rv[i], px[i]);
             }
             return 0;
         }
@@ -594,6 +635,49 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
         for (int i = 0; i < PXT; i++) {
             if (DEPTH == GF_DEPTH_U8) interp_u8_interior<HI16>(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i], px[i]);
             else                      interp_u16_interior(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i], px[i]);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const int sx = (int)(int16_t)(iu[i] >> INTER_BITS), sy = (int)(int16_t)(iv[i] >> INTER_BITS);   // Q1: wrapping cast
+            const int a = (iv[i] & 31)*32 + (iu[i] & 31);
+            const Px3 o = bilinear_px<DEPTH, BORDER>(s, sx, sy, a, cval[0], cval[1], cval[2]);
+            if (!o.ok) keep |= 1u << i;
+            px[i][0] = HI16 ? o.c0 << 16 : o.c0; px[i][1] = HI16 ? o.c1 << 16 : o.c1; px[i][2] = HI16 ? o.c2 << 16 : o.c2;
+        }
+    }
+    return keep;
+}
+
+// remap4 in two phases, so that a thread can put other work (the next row's coordinates) between issuing its tap loads
+// and using them.  fetch4 returns whether all PXT pixels are interior (then T holds their taps, loads in flight).
+template <int DEPTH>
+__device__ __forceinline__ bool fetch4(const SrcImg& s, const int* iu, const int* iv, typename TapsT<DEPTH>::T* T)
+{
+    const unsigned w1 = (unsigned)(s.w - 1) - ((DEPTH == GF_DEPTH_U8 && s.w > 1) ? 1u : 0u), h1 = (unsigned)(s.h - 1);
+    const unsigned umax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
+    const unsigned vmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
+    const bool interior = umax < (w1 << INTER_BITS) && vmax < (h1 << INTER_BITS);
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            if constexpr (DEPTH == GF_DEPTH_U8) T[i] = fetch_u8_interior(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i]);
+            else                                T[i] = fetch_u16_interior(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i]);
+        }
+    }
+    return interior;
+}
+
+template <int DEPTH, int BORDER, bool HI16>
+__device__ __forceinline__ unsigned finish4(const SrcImg& s, const int* iu, const int* iv, const int* cval, bool interior,
+                                            const typename TapsT<DEPTH>::T* T, int (*px)[3])
+{
+    unsigned keep = 0;
+    if (interior) {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            if constexpr (DEPTH == GF_DEPTH_U8) bilin_u8_rows<HI16>(T[i].a, T[i].b, (unsigned)iu[i], (unsigned)iv[i], px[i]);
+            else                                bilin_u16_float(T[i].a, T[i].b, iu[i] & 31, iv[i] & 31, px[i]);
         }
     } else {
 #pragma unroll
@@ -697,14 +781,20 @@ __device__ __forceinline__ bool tile_of_padded_id(unsigned w, int tiles_x, int t
     return true;
 }
 
+#ifndef GF_K1_PIPELINE
+#define GF_K1_PIPELINE 0
+#endif
+#ifndef GF_K1_WAVES
+#define GF_K1_WAVES 5
+#endif
 template <int DEPTH, int BORDER>
-__global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+__global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
                                                              unsigned tiles_pad, unsigned n_work)
 {
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     load_lens_table(lens, s_tab);
     constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int lx = threadIdx.x & (TPR - 1), ly = threadIdx.x / TPR;
 #pragma unroll 1
     for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
         const unsigned frame = v / tiles_pad;
@@ -714,39 +804,65 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate(RemapArgs A, const X
         if (x0 >= A.dw) continue;
         const Xf& xf = xfs[frame];
         const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+#if GF_K1_PIPELINE
+        // Software pipeline over the tile's passes: the taps of row y are in flight while the coordinates of row
+        // y + PASS_H are computed, so a wave overlaps its own gather latency with its own arithmetic.
+        int y = ty*TILE_H + ly;
+        if (y >= A.dh) continue;
+        int iu[PXT], iv[PXT];
+        coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu, iv);
+#pragma unroll 1
+        for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
+            typename TapsT<DEPTH>::T T[PXT];
+            const bool interior = fetch4<DEPTH>(s, iu, iv, T);
+            const int yn = y + PASS_H;
+            const bool more = pass + 1 < TILE_H/PASS_H && yn < A.dh;
+            int nu[PXT], nv[PXT];
+            if (more) coord_q5x4(row_consts(xf, yn), xf, lk, s_tab, x0, nu, nv);
+            int px[PXT][3];
+            const unsigned keep = finish4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, interior, T, px);
+            uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+            store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+            if (!more) break;
+#pragma unroll
+            for (int i = 0; i < PXT; i++) { iu[i] = nu[i]; iv[i] = nv[i]; }
+            y = yn;
+        }
+#else
 #pragma unroll 1
         for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
             const int y = ty*TILE_H + pass*PASS_H + ly;
             if (y >= A.dh) break;
-            const RowC rc = row_consts(xf, y);
             int iu[PXT], iv[PXT];
-            coord_q5x4(rc, xf, lk, s_tab, x0, iu, iv);
+            coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu, iv);
             int px[PXT][3];
             const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
             uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
             store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
         }
+#endif
     }
 }
 
-// K1-LDS: the same work with the source taps staged through LDS.  A gather straight from global memory costs the CU's
-// texture-address unit ~0.7 cycles per LANE (measured: 43 TA-busy cycles per 64-lane 8-byte load, TA busy 87 % of
-// the direct kernel's time), so the direct kernel cannot drop below ~17 us per 4K frame.  Here the workgroup
-//   1. estimates the source box of its 64 x (16*NPASS) output tile from 8 boundary samples (corners + edge midpoints,
-//      +-1 px margin, clamped to the frame),
-//   2. copies that box into LDS with aligned 16-byte loads (one lane-access per 5.3 source pixels instead of two per
-//      output pixel), repacking 3-byte pixels to one dword each on the way,
-//   3. gathers the taps with aligned ds_read2_b32.
+// K1-LDS: the same work with the source taps staged through LDS.  The vector-memory path returns ~11 bytes per clock
+// and CU to gathers that miss L1 (measured: 47 TD-busy cycles per 64-lane 8-byte load), and the direct kernel asks it for
+// 16 bytes per output pixel; that, not HBM, bounds it.  Here every workgroup, per 64 x 32 output tile,
+//   1. estimates the tile's source box from 8 boundary samples (corners + edge midpoints, +-1 px margin, clamped),
+//   2. copies the box into LDS with aligned 16-byte loads (each source byte requested once), repacking 3-byte pixels
+//      to one dword each on the way,
+//   3. gathers the taps from LDS (aligned ds_read2_b32).
 // A pixel whose taps fall outside the box (the estimate is not a bound) takes the direct path, so results never depend
-// on the estimate.  Needs a 16-byte aligned frame base and row pitch (host-checked); a box that does not fit
-// LDS_SRC_BYTES (strong zoom-out or rotation) turns the whole workgroup to the direct path.
+// on the estimate.  Needs a 16-byte aligned frame base, row pitch and frame stride (host-checked); a box that does not
+// fit LDS_SRC_BYTES (strong zoom-out or rotation) sends the whole tile down the direct path.
+// Persistent like K1: the lens table is loaded once per workgroup; three barriers per tile.
 constexpr int LT_W = 64;
 constexpr int LT_TPR = LT_W/PXT;                 // 16 threads per output row
 constexpr int LT_RPP = BLOCK/LT_TPR;             // 16 rows per pass
-constexpr int LDS_SRC_BYTES = 31232;             // 8 KB lens table + 30.5 KB source box = 4 workgroups per CU
+constexpr int LDS_SRC_BYTES = 24576;             // 16 KB lens table + 24 KB source box = 3 workgroups per CU
 
 template <int DEPTH, int BORDER, int NPASS>
-__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk)
+__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                                 unsigned tiles_pad, unsigned n_work)
 {
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     __shared__ uint4 s_src[LDS_SRC_BYTES/16];
@@ -754,89 +870,99 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, con
     constexpr int PB = DEPTH == GF_DEPTH_U8 ? 3 : 6;           // source bytes per pixel
     constexpr int LPB = DEPTH == GF_DEPTH_U8 ? 4 : 8;          // LDS bytes per pixel
     constexpr int LT_H = LT_RPP*NPASS;
+    constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
     const int tid = threadIdx.x;
-    if (tid < 4) s_box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
     load_lens_table(lens, s_tab);                    // ends with __syncthreads()
-    int tx, ty;
-    tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
-    const int frame = blockIdx.y;
     const int lx = tid & (LT_TPR - 1), ly = tid / LT_TPR;
-    const int x0 = tx*LT_W + lx*PXT;
-    const Xf& xf = xfs[frame];
-    const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
 
-    if (tid < 8) {                                   // boundary samples: k = 0..7 around the tile's rim
-        const int xa = tx*LT_W, xb = min(xa + LT_W - 1, A.dw - 1), ya = ty*LT_H, yb = min(ya + LT_H - 1, A.dh - 1);
-        const int k = tid < 4 ? tid : tid + 1;       // skip the centre of the 3x3 grid
-        const int kx = k % 3, ky = k / 3;
-        const int px_ = kx == 0 ? xa : kx == 1 ? (xa + xb) >> 1 : xb, py_ = ky == 0 ? ya : ky == 1 ? (ya + yb) >> 1 : yb;
-        int su, sv;
-        coord_q5(row_consts(xf, py_), xf, lk, s_tab, px_, su, sv);
-        su >>= INTER_BITS; sv >>= INTER_BITS;
-        atomicMin(&s_box[0], su); atomicMax(&s_box[1], su); atomicMin(&s_box[2], sv); atomicMax(&s_box[3], sv);
-    }
+#pragma unroll 1
+    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const unsigned frame = v / tiles_pad;
+        int tx, ty;
+        if (!tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) continue;     // uniform
+        const int x0 = tx*LT_W + lx*PXT;
+        const Xf& xf = xfs[frame];
+        const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
 
-    int iu[NPASS][PXT], iv[NPASS][PXT];
-#pragma unroll
-    for (int p = 0; p < NPASS; p++) {
-        const int y = ty*LT_H + p*LT_RPP + ly;
-        if (x0 < A.dw && y < A.dh) {
-            coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu[p], iv[p]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < PXT; i++) iu[p][i] = iv[p][i] = 0;
+        __syncthreads();                             // the previous tile's LDS taps and s_box are no longer read
+        if (tid < 4) s_box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+        if (tid < 8) {                               // boundary samples: k = 0..7 around the tile's rim (same wave as the reset)
+            const int xa = tx*LT_W, xb = min(xa + LT_W - 1, A.dw - 1), ya = ty*LT_H, yb = min(ya + LT_H - 1, A.dh - 1);
+            const int k = tid < 4 ? tid : tid + 1;   // skip the centre of the 3x3 grid
+            const int kx = k % 3, ky = k / 3;
+            const int px_ = kx == 0 ? xa : kx == 1 ? (xa + xb) >> 1 : xb, py_ = ky == 0 ? ya : ky == 1 ? (ya + yb) >> 1 : yb;
+            int su, sv;
+            coord_q5(row_consts(xf, py_), xf, lk, s_tab, px_, su, sv);
+            su >>= INTER_BITS; sv >>= INTER_BITS;
+            atomicMin(&s_box[0], su); atomicMax(&s_box[1], su); atomicMin(&s_box[2], sv); atomicMax(&s_box[3], sv);
         }
-    }
-    __syncthreads();
 
-    LdsBox L{(lds_u32)s_src, 0, 0, 0, 0, 0, 0, false};
-    {
-        // tap positions: samples +-1 px, clamped to the positions whose four taps are inside the frame
-        const int bx0 = max(s_box[0] - 1, 0), bx1 = min(s_box[1] + 1, s.w - 2);
-        const int by0 = max(s_box[2] - 1, 0), by1 = min(s_box[3] + 1, s.h - 2);
-        if (bx0 <= bx1 && by0 <= by1) {
-            const int bx0a = bx0 & ~15;                              // 16-pixel units: 48 (u8) / 96 (u16) source bytes
-            const unsigned units = (unsigned)(bx1 + 2 - bx0a + 15) >> 4, rows = (unsigned)(by1 - by0 + 2), pitch = units*16u;
-            if (rows*pitch*LPB <= (unsigned)LDS_SRC_BYTES) {
-                const size_t valid = (size_t)(s.h - 1)*s.step + (size_t)s.w*PB;      // bytes of the frame
-                for (unsigned r = (unsigned)tid >> 3; r < rows; r += BLOCK/8)
-                    for (unsigned k = (unsigned)tid & 7u; k < units; k += 8) {
-                        const size_t goff = (size_t)(by0 + (int)r)*s.step + (size_t)(bx0a + 16*(int)k)*PB;
-                        uint32_t d[PB*4];
+        int iu[NPASS][PXT], iv[NPASS][PXT];
 #pragma unroll
-                        for (int c = 0; c < PB; c++) {
-                            // aligned 16-byte chunk: if it starts inside the frame it lies in the frame's pages
-                            uint4 v = make_uint4(0, 0, 0, 0);
-                            if (goff + 16*c < valid) v = *(const uint4*)(s.base + goff + 16*c);
-                            d[4*c] = v.x; d[4*c+1] = v.y; d[4*c+2] = v.z; d[4*c+3] = v.w;
-                        }
-                        uint4* dst = s_src + ((r*pitch + 16u*k)*LPB >> 4);
-                        if (DEPTH == GF_DEPTH_U8) {
+        for (int p = 0; p < NPASS; p++) {
+            const int y = ty*LT_H + p*LT_RPP + ly;
+            if (x0 < A.dw && y < A.dh) {
+                coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu[p], iv[p]);
+            } else {
 #pragma unroll
-                            for (int m = 0; m < 4; m++)     // 4 pixels = 3 dwords -> 4 dwords (byte 3 of each is don't-care)
-                                dst[m] = make_uint4(d[3*m], __builtin_amdgcn_alignbyte(d[3*m+1], d[3*m], 3),
-                                                    __builtin_amdgcn_alignbyte(d[3*m+2], d[3*m+1], 2), d[3*m+2] >> 8);
-                        } else {
-#pragma unroll
-                            for (int m = 0; m < 8; m++)     // 2 pixels = 3 dwords -> 4 dwords
-                                dst[m] = make_uint4(d[3*m], d[3*m+1], __builtin_amdgcn_alignbit(d[3*m+2], d[3*m+1], 16), d[3*m+2] >> 16);
-                        }
-                    }
-                L.x0 = bx0; L.y0 = by0; L.nx = (unsigned)(bx1 - bx0 + 1); L.ny = (unsigned)(by1 - by0 + 1);
-                L.pitch = pitch; L.base = -(by0*(int)pitch) - bx0a; L.on = true;
+                for (int i = 0; i < PXT; i++) iu[p][i] = iv[p][i] = 0;
             }
         }
-    }
-    __syncthreads();
+        __syncthreads();
+
+        LdsBox L{(lds_u32)s_src, 0, 0, 0, 0, 0, 0, false};
+        {
+            // tap positions: samples +-1 px, clamped to the positions whose four taps are inside the frame.  The four
+            // values are the same in every lane: keep them in scalar registers.
+            const int smin_x = __builtin_amdgcn_readfirstlane(s_box[0]), smax_x = __builtin_amdgcn_readfirstlane(s_box[1]);
+            const int smin_y = __builtin_amdgcn_readfirstlane(s_box[2]), smax_y = __builtin_amdgcn_readfirstlane(s_box[3]);
+            const int bx0 = max(smin_x, 1) - 1, bx1 = min(smax_x, s.w - 3) + 1;       // max(a - 1, 0), min(a + 1, w - 2) without overflow
+            const int by0 = max(smin_y, 1) - 1, by1 = min(smax_y, s.h - 3) + 1;
+            if (bx0 <= bx1 && by0 <= by1) {
+                const int bx0a = bx0 & ~15;                              // 16-pixel units: 48 (u8) / 96 (u16) source bytes
+                const unsigned units = (unsigned)(bx1 + 2 - bx0a + 15) >> 4, rows = (unsigned)(by1 - by0 + 2), pitch = units*16u;
+                if ((unsigned long long)rows*pitch*LPB <= (unsigned)LDS_SRC_BYTES) {
+                    const size_t valid = (size_t)(s.h - 1)*s.step + (size_t)s.w*PB;      // bytes of the frame
+                    for (unsigned r = (unsigned)tid >> 3; r < rows; r += BLOCK/8)
+                        for (unsigned k = (unsigned)tid & 7u; k < units; k += 8) {
+                            const size_t goff = (size_t)(by0 + (int)r)*s.step + (size_t)(bx0a + 16*(int)k)*PB;
+                            uint32_t d[PB*4];
+#pragma unroll
+                            for (int c = 0; c < PB; c++) {
+                                // aligned 16-byte chunk: if it starts inside the frame it lies in the frame's pages
+                                uint4 q = make_uint4(0, 0, 0, 0);
+                                if (goff + 16*c < valid) q = *(const uint4*)(s.base + goff + 16*c);
+                                d[4*c] = q.x; d[4*c+1] = q.y; d[4*c+2] = q.z; d[4*c+3] = q.w;
+                            }
+                            uint4* dst = s_src + ((r*pitch + 16u*k)*LPB >> 4);
+                            if (DEPTH == GF_DEPTH_U8) {
+#pragma unroll
+                                for (int m = 0; m < 4; m++)     // 4 pixels = 3 dwords -> 4 dwords (byte 3 of each is don't-care)
+                                    dst[m] = make_uint4(d[3*m], __builtin_amdgcn_alignbyte(d[3*m+1], d[3*m], 3),
+                                                        __builtin_amdgcn_alignbyte(d[3*m+2], d[3*m+1], 2), d[3*m+2] >> 8);
+                            } else {
+#pragma unroll
+                                for (int m = 0; m < 8; m++)     // 2 pixels = 3 dwords -> 4 dwords
+                                    dst[m] = make_uint4(d[3*m], d[3*m+1], __builtin_amdgcn_alignbit(d[3*m+2], d[3*m+1], 16), d[3*m+2] >> 16);
+                            }
+                        }
+                    L.X0 = (unsigned)bx0 << INTER_BITS; L.Y0 = (unsigned)by0 << INTER_BITS;
+                    L.NX = (unsigned)(bx1 - bx0 + 1) << INTER_BITS; L.NY = (unsigned)(by1 - by0 + 1) << INTER_BITS;
+                    L.pitch = pitch; L.xoff = (unsigned)(bx0 - bx0a); L.on = true;
+                }
+            }
+        }
+        __syncthreads();
 
 #pragma unroll
-    for (int p = 0; p < NPASS; p++) {
-        const int y = ty*LT_H + p*LT_RPP + ly;
-        if (x0 < A.dw && y < A.dh) {
-            int px[PXT][3];
-            const unsigned keep = remap4<DEPTH, BORDER>(s, iu[p], iv[p], A.cval, px, L);
-            uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
-            store_px<DEPTH>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+        for (int p = 0; p < NPASS; p++) {
+            const int y = ty*LT_H + p*LT_RPP + ly;
+            if (x0 < A.dw && y < A.dh) {
+                int px[PXT][3];
+                const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu[p], iv[p], A.cval, px, L);
+                uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+                store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+            }
         }
     }
 }
@@ -851,7 +977,7 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, c
     int tx, ty;
     tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
     const int g = blockIdx.y;
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int lx = threadIdx.x & (TPR - 1), ly = threadIdx.x / TPR;
     const int x0 = tx*TILE_W + lx*PXT;
     if (x0 >= A.dw) return;
     const double wgt = 1.0/(double)n_blend;       // Python: 1/(self.hyperlapse_num_blended_frames)
@@ -893,7 +1019,7 @@ __global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8
 {
     int tx, ty;
     tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
-    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+    const int lx = threadIdx.x & (TPR - 1), ly = threadIdx.x / TPR;
     const int x0 = tx*TILE_W + lx*PXT;
     if (x0 >= A.dw) return;
     const SrcImg s{A.src, A.sw, A.sh, A.sstep};
@@ -1438,8 +1564,14 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     if (aligned16 && g_use_lds_tiles) {               // LDS-staged source taps
         const int npass = depth == GF_DEPTH_U8 ? 2 : 1;
         A.tiles_x = (dw + LT_W - 1)/LT_W; A.tiles_y = (dh + LT_RPP*npass - 1)/(LT_RPP*npass);
-        dim3 grid(A.tiles_x*A.tiles_y, n_frames);
-#define LAUNCH_LDS(DEPTH_, BORDER_, NP_) hipLaunchKernelGGL((k_undistort_rotate_lds<DEPTH_, BORDER_, NP_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk)
+        const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
+        const unsigned long long n_work = (unsigned long long)tiles_pad*(unsigned)n_frames;
+        if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many tiles in one call (%lld)", "gf_undistort_rotate_c3", (long long)n_work);
+        unsigned blocks = (unsigned)c->n_cu*WG_PER_CU_LDS & ~(unsigned)(NXCD - 1);
+        if (blocks == 0) blocks = NXCD;
+        if (blocks > n_work) blocks = (unsigned)n_work;
+        dim3 grid(blocks, 1);
+#define LAUNCH_LDS(DEPTH_, BORDER_, NP_) hipLaunchKernelGGL((k_undistort_rotate_lds<DEPTH_, BORDER_, NP_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work)
         if (depth == GF_DEPTH_U8) {
             if (border == GF_BORDER_CONSTANT) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_CONSTANT, 2);
             else if (border == GF_BORDER_REPLICATE) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_REPLICATE, 2);

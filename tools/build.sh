@@ -12,6 +12,13 @@ for v in "$@"; do
     ldsaligned) hipcc $F -DGF_ABL_LDS_ALIGNED -o tools/_build/lib_ldsaligned.so gyroflow_amd/csrc/gfremap.hip ;;
     noatomic) hipcc $F -DGF_ABL_NO_ATOMIC -o tools/_build/lib_noatomic.so gyroflow_amd/csrc/gfremap.hip ;;
     x2) hipcc $F -DGF_EXP_X2 -o tools/_build/lib_x2.so gyroflow_amd/csrc/gfremap.hip ;;
+    noload) hipcc $F -DGF_ABL_NOLOAD -o tools/_build/lib_noload.so gyroflow_amd/csrc/gfremap.hip ;;
+    k1_*) # k1_<pipeline>_<waves>, e.g. k1_0_8
+        IFS=_ read -r _ pl wv <<< "$v"
+        hipcc $F -DGF_K1_PIPELINE=$pl -DGF_K1_WAVES=$wv -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
+    tile_*) # tile_<W>_<H>
+        IFS=_ read -r _ tw th <<< "$v"
+        hipcc $F -DGF_TILE_W=$tw -DGF_TILE_H=$th -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
     both)     hipcc $F -DGF_ABL_NOMATH -DGF_ABL_NOGATHER -o tools/_build/lib_both.so gyroflow_amd/csrc/gfremap.hip ;;
   esac
 done

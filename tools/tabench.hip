@@ -27,10 +27,11 @@ template <> __device__ __forceinline__ uint32_t ld<16>(const uint8_t* p) { P4 v 
 
 // Each lane: address = base + row*rowstep + lane*lane_stride + small per-iteration shift; 8 independent loads per iteration.
 template <int W>
-__global__ void __launch_bounds__(256) k_gather(const uint8_t* __restrict__ base, uint32_t* out, int lane_stride, int rowstep, int iters, uint32_t region)
+__global__ void __launch_bounds__(256) k_gather(const uint8_t* __restrict__ base, uint32_t* out, int lane_stride, int rowstep, int iters, uint32_t region, int active_mod)
 {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t acc = 0;
+    if ((int)((lane*7u + 3u) % 16u) >= active_mod) { out[blockIdx.x*256 + threadIdx.x] = 0; return; }   // active_mod/16 of the lanes load
     uint32_t off0 = lane*lane_stride + wave*rowstep*8 + (blockIdx.x & 7)*64;
     for (int it = 0; it < iters; it++) {
         uint32_t o = off0 + (it & 15)*3;
@@ -44,19 +45,61 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t* __restrict__ base
     out[blockIdx.x*256 + threadIdx.x] = acc;
 }
 
+// Streaming variant (cold lines): a wave walks down an image-like region; per "pass" it issues 8 loads the way the fused
+// kernel does for 4 pixels x 2 source rows.  layout 0: a lane owns 4 adjacent pixels (lane stride 12 B, the 4 loads of a
+// row are 3 B apart); layout 1: adjacent lanes own adjacent pixels (lane stride 3 B, the 4 loads of a row are 192 B apart).
 template <int W>
-static void run(const uint8_t* buf, uint32_t* out, int lane_stride, int rowstep, uint32_t region)
+__global__ void __launch_bounds__(256) k_stream(const uint8_t* __restrict__ base, uint32_t* out, int layout, int rowstep, int rows, size_t region)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    // each block owns a 768-byte wide column strip; its 4 waves take rows y = wave, wave + 4, ...
+    size_t col = ((size_t)blockIdx.x*768u) % (size_t)(rowstep - 1024);
+    size_t strip = ((size_t)blockIdx.x*768u) / (size_t)(rowstep - 1024);
+    const uint8_t* p0 = base + (strip*(size_t)rows*rowstep) % region + col;
+    for (int y = wave; y < rows; y += 4) {
+        const uint8_t* r0 = p0 + (size_t)y*rowstep;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const unsigned o = layout == 0 ? lane*12u + i*3u : lane*3u + i*192u;
+            acc ^= ld<W>(r0 + o);
+            acc ^= ld<W>(r0 + rowstep + o);
+        }
+    }
+    out[blockIdx.x*256 + threadIdx.x] = acc;
+}
+
+template <int W>
+static void run_stream(const uint8_t* buf, uint32_t* out, int layout, int rowstep, size_t region)
+{
+    const int rows = 512, blocks = 256*8;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_stream<W>, dim3(blocks), dim3(256), 0, 0, buf, out, layout, rowstep, 8, region);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_stream<W>, dim3(blocks), dim3(256), 0, 0, buf, out, layout, rowstep, rows, region);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr_per_cu = (double)blocks*rows*8/256.0;
+    const double ns = ms*1e6/instr_per_cu;
+    printf("  stream layout %d width %2d B: %6.2f ns = %5.1f cycles (2.4 GHz) per wave-instr per CU; %.0f GB/s of distinct bytes\n", layout, W, ns, ns*2.4,
+           (double)blocks*rows*768.0/(ms*1e-3)/1e9);
+}
+
+template <int W>
+static void run(const uint8_t* buf, uint32_t* out, int lane_stride, int rowstep, uint32_t region, int active_mod = 16)
 {
     const int iters = 2000, blocks = 256*8;          // 8 blocks of 4 waves per CU
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_gather<W>, dim3(blocks), dim3(256), 0, 0, buf, out, lane_stride, rowstep, 10, region);
+    hipLaunchKernelGGL(k_gather<W>, dim3(blocks), dim3(256), 0, 0, buf, out, lane_stride, rowstep, 10, region, active_mod);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_gather<W>, dim3(blocks), dim3(256), 0, 0, buf, out, lane_stride, rowstep, iters, region);
+    hipLaunchKernelGGL(k_gather<W>, dim3(blocks), dim3(256), 0, 0, buf, out, lane_stride, rowstep, iters, region, active_mod);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double instr_per_cu = (double)blocks*4*iters*8/256.0;
     const double ns = ms*1e6/instr_per_cu;
+    if (active_mod != 16) printf("  [%2d/16 lanes active]", active_mod);
     printf("  width %2d B  lane stride %3d B : %6.2f ns = %5.1f cycles per wave-instr per CU  (%5.1f B/clk/CU)\n", W, lane_stride, ns, ns*2.4, 64.0*W/(ns*2.4));
 }
 
@@ -67,7 +110,7 @@ int main()
     CK(hipMalloc(&buf, region + 65536)); CK(hipMemset(buf, 1, region + 65536));
     CK(hipMalloc(&out, 256*8*256*4));
     const int rowstep = 11520;             // a 4K u8 row
-    const int strides[] = {3, 4, 6, 12, 16, 24, 64};
+    const int strides[] = {12};
     for (int s : strides) {
         printf("lane stride %d B\n", s);
         run<2>(buf, out, s, rowstep, region);
@@ -76,5 +119,14 @@ int main()
         run<12>(buf, out, s, rowstep, region);
         run<16>(buf, out, s, rowstep, region);
     }
+    {
+        const size_t big = (size_t)1 << 31;
+        uint8_t* b2; CK(hipMalloc(&b2, big + (1 << 24))); CK(hipMemset(b2, 1, big + (1 << 24)));
+        printf("streaming (cold) gathers, 4 px x 2 rows per lane and pass\n");
+        for (int layout = 0; layout < 2; layout++) { run_stream<4>(b2, out, layout, rowstep, big); run_stream<8>(b2, out, layout, rowstep, big); }
+        CK(hipFree(b2));
+    }
+    printf("partial exec masks, width 8, lane stride 12\n");
+    for (int a : {16, 12, 8, 4, 2, 1}) run<8>(buf, out, 12, rowstep, region, a);
     return 0;
 }
