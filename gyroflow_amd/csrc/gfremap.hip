@@ -1110,15 +1110,19 @@ __device__ __forceinline__ int border_interp(int p, int len, int border1)
     return -1;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __restrict__ src, int sw, int sh, size_t sstep,
-                                                             uint8_t* dst, int dw, int dh, size_t dstep,
+// SEP = true: separable maps (NonlinearStretch): mx is one row of dw floats, my one column of dh floats; blockIdx.z = frame.
+template <bool SEP>
+__global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __restrict__ src, int sw, int sh, size_t sstep, size_t sframe,
+                                                             uint8_t* dst, int dw, int dh, size_t dstep, size_t dframe,
                                                              const uint8_t* __restrict__ mx, size_t mxstep,
                                                              const uint8_t* __restrict__ my, size_t mystep,
                                                              const int16_t* __restrict__ tab, int border, int c0, int c1, int c2)
 {
     const int dx = blockIdx.x*64 + (threadIdx.x & 63), dy = blockIdx.y*4 + (threadIdx.x >> 6);
     if (dx >= dw || dy >= dh) return;
-    const float fxm = ((const float*)(mx + (size_t)dy*mxstep))[dx], fym = ((const float*)(my + (size_t)dy*mystep))[dx];
+    src += (size_t)blockIdx.z*sframe; dst += (size_t)blockIdx.z*dframe;
+    const float fxm = SEP ? ((const float*)mx)[dx] : ((const float*)(mx + (size_t)dy*mxstep))[dx];
+    const float fym = SEP ? ((const float*)my)[dy] : ((const float*)(my + (size_t)dy*mystep))[dx];
     const int isx = cv_round_f(__fmul_rn(fxm, 32.f)), isy = cv_round_f(__fmul_rn(fym, 32.f));
     const int a = (isy & 31)*32 + (isx & 31);
     const int sx = sat_s16(isx >> INTER_BITS) - 1, sy = sat_s16(isy >> INTER_BITS) - 1;
@@ -1509,6 +1513,9 @@ GF_API int gf_remap_linear_c3(void* ctx, int depth, const void* src, int sw, int
     return GF_OK;
 }
 
+static int fused_checks(const char* fn, void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                        void* dst, int dw, int dh, size_t dstep, size_t dframe, const void* xf, long long n_in, long long n_out, int border);
+
 GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep,
                                 uint8_t* dst, int dw, int dh, size_t dstep,
                                 const float* mx, size_t mxs, const float* my, size_t mys,
@@ -1525,8 +1532,25 @@ GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, in
     int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
     DeviceGuard dg(((Ctx*)ctx)->device);
     dim3 grid((dw + 63)/64, (dh + 3)/4);
-    hipLaunchKernelGGL(k_remap_cubic_u8c3, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, dst, dw, dh, dstep,
+    hipLaunchKernelGGL(k_remap_cubic_u8c3<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, (size_t)0, dst, dw, dh, dstep, (size_t)0,
                        (const uint8_t*)mx, mxs, (const uint8_t*)my, mys, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
+    HIP_TRY(hipGetLastError());
+    return GF_OK;
+}
+
+GF_API int gf_superview_cubic_u8c3(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep, size_t sframe,
+                                   uint8_t* dst, int dw, int dh, size_t dstep, size_t dframe,
+                                   const float* mapx_row, const float* mapy_col, int n_frames,
+                                   int border, const double bv[4], gf_stream_t stream)
+{
+    int rc = fused_checks("gf_superview_cubic_u8c3", ctx, GF_DEPTH_U8, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, mapx_row, n_frames, n_frames, border);
+    if (rc) return rc;
+    if (!mapy_col || ((uintptr_t)mapx_row & 3) || ((uintptr_t)mapy_col & 3)) return fail(GF_ERR_INVALID_ARG, "%s: null or misaligned map", "gf_superview_cubic_u8c3");
+    int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
+    DeviceGuard dg(((Ctx*)ctx)->device);
+    dim3 grid((dw + 63)/64, (dh + 3)/4, n_frames);
+    hipLaunchKernelGGL(k_remap_cubic_u8c3<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe,
+                       (const uint8_t*)mapx_row, (size_t)0, (const uint8_t*)mapy_col, (size_t)0, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }

@@ -253,6 +253,35 @@ def undistort_rotate_blend(src, D, xforms_dev, out_size, frames_per_group, n_ble
     return d
 
 
+def superview_cubic(src, mapx_row, mapy_col, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+    """cv2.remap(img, map1, map2, cv2.INTER_CUBIC) for separable maps (map1[y, x] = mapx_row[x], map2[y, x] = mapy_col[y]),
+    as NonlinearStretch builds them (nonlinear_stretch.py:58-100,130), batched: src CUDA uint8 [N,H,W,3] or [H,W,3];
+    mapx_row / mapy_col CUDA float32 vectors of the output width / height."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda):
+        raise TypeError("superview_cubic works on CUDA tensors")
+    dev = src.device
+    s = _frames4(src, "src")
+    if s.dtype != torch.uint8:
+        raise TypeError("INTER_CUBIC is implemented for uint8 only")
+    n = s.shape[0]
+    if mapx_row.dtype != torch.float32 or mapy_col.dtype != torch.float32 or mapx_row.dim() != 1 or mapy_col.dim() != 1:
+        raise ValueError("mapx_row / mapy_col must be float32 vectors")
+    mx = mapx_row.to(dev).contiguous(); my = mapy_col.to(dev).contiguous()
+    dw, dh = mx.numel(), my.numel()
+    if dst is None:
+        d = torch.zeros((n, dh, dw, 3), dtype=torch.uint8, device=dev)
+    else:
+        d = _frames4(dst, "dst")
+        if tuple(d.shape) != (n, dh, dw, 3) or d.dtype != torch.uint8 or d.device != dev:
+            raise ValueError("dst has the wrong shape/dtype/device")
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gf_superview_cubic_u8c3(ctx, _ptr(s), s.shape[2], s.shape[1], s.stride(1), s.stride(0), _ptr(d), dw, dh,
+                                               d.stride(1), d.stride(0), _ptr(mx), _ptr(my), n, int(borderMode),
+                                               _lib.border_value(borderValue), _stream(dev)))
+    return d if (src.dim() == 4) else d[0]
+
+
 def blend_accumulate(frame, acc, weight, reset):
     """acc (CUDA float64, same number of elements as frame) = (acc*0 if reset else acc) + weight*frame."""
     dev = frame.device

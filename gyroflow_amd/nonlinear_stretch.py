@@ -68,6 +68,13 @@ class NonlinearStretch:
                               torch.from_numpy(np.ascontiguousarray(self.map2.astype('float32'))).to(device))
         return self._dev_maps
 
+    def apply_stretch_batch(self, frames):
+        """Stretch CUDA uint8 frames [N,H,W,3] (or one [H,W,3]) in one launch.  recompute_maps() makes map1 a function of
+        the column and map2 a function of the row, so the kernel reads one row / one column of them instead of the
+        two full-size float32 maps; the result equals cv2.remap(img, map1, map2, cv2.INTER_CUBIC) per frame."""
+        m1, m2 = self._maps_on(frames.device)
+        return cv.superview_cubic(frames, m1[0, :], m2[:, 0])
+
     def apply_stretch(self, img, show_protected=False):
         """Stretch one uint8 HxWx3 image (numpy -> numpy, CUDA tensor -> CUDA tensor)."""
         if isinstance(img, torch.Tensor) and img.is_cuda:

@@ -113,6 +113,16 @@ GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, in
                                 const float* mapx, size_t mapx_step, const float* mapy, size_t mapy_step,
                                 int border, const double border_value_host[4], gf_stream_t stream);
 
+/* NonlinearStretch.apply_stretch (nonlinear_stretch.py:120-130) for a batch of frames, with the maps recompute_maps()
+ * builds (nonlinear_stretch.py:58-100) passed in their separable form: map1 depends on the column only, map2 on the row
+ * only, so mapx_row = map1[0, :] (dw floats) and mapy_col = map2[:, 0] (dh floats), both DEVICE pointers.  Same
+ * arithmetic and result as gf_remap_cubic_u8c3_f32maps with the full maps; no 2-D map is read (8 bytes per pixel less).
+ * Frame i reads src + i*src_frame_stride and writes dst + i*dst_frame_stride. */
+GF_API int gf_superview_cubic_u8c3(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                                   uint8_t* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                                   const float* mapx_row, const float* mapy_col, int n_frames,
+                                   int border, const double border_value_host[4], gf_stream_t stream);
+
 /* The fused hot path: for each of n_frames frames, get_maps() + cv2.remap(INTER_LINEAR) in one kernel; the
  * fixed-point map is computed per output pixel in registers and never stored
  *   replaces calibrate_video.py:383 + stabilizer.py:1442-1443 (the body of the render loop, stabilizer.py:1423-1443).

@@ -253,6 +253,33 @@ def test_nonlinear_stretch_apply(gpu, orc):
     np.testing.assert_array_equal(got_t.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize("cfg", [dict(safe=0.0, expo=2), dict(safe=0.3, expo=1.7), dict(safe=0.999, expo=3)])
+def test_superview_separable_maps_batched(gpu, orc, cfg):
+    """gf_superview_cubic_u8c3 (batched, separable maps) == bicubic remap with the full NonlinearStretch maps, per frame
+    and bit for bit; borders included (the stretch maps start at -0.5 px)."""
+    from gyroflow_amd import NonlinearStretch, synthetic_frames, cv
+    ns = NonlinearStretch((200, 150), (288, 162), safe_area=0, expo=cfg["expo"])
+    ns.set_safe_area(cfg["safe"])
+    ns.recompute_maps()
+    assert np.all(ns.map1 == ns.map1[0:1, :]) and np.all(ns.map2 == ns.map2[:, 0:1])      # separable by construction
+    frames = np.stack(synthetic_frames(200, 150, n=3, seed=5))
+    got = ns.apply_stretch_batch(torch.from_numpy(frames).to(gpu)).cpu().numpy()
+    assert got.shape == (3, 162, 288, 3)
+    for i in range(3):
+        np.testing.assert_array_equal(got[i], orc.remap_cubic(frames[i], ns.map1, ns.map2))
+    one = ns.apply_stretch_batch(torch.from_numpy(frames[1]).to(gpu)).cpu().numpy()
+    np.testing.assert_array_equal(one, got[1])
+    # other borders + preset dst through the cv-level call
+    prev = torch.from_numpy(np.stack(synthetic_frames(288, 162, n=3, seed=9))).to(gpu)
+    for border in (1, 5):
+        d = prev.clone()
+        cv.superview_cubic(torch.from_numpy(frames).to(gpu), torch.from_numpy(ns.map1[0]).to(gpu), torch.from_numpy(ns.map2[:, 0].copy()).to(gpu),
+                           dst=d, borderMode=border)
+        for i in range(3):
+            want = orc.remap_cubic(frames[i], ns.map1, ns.map2, dst=prev[i].cpu().numpy().copy(), borderMode=border)
+            np.testing.assert_array_equal(d[i].cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("dtype,tdtype", [(np.uint8, torch.uint8), (np.uint16, torch.uint16)])
 @pytest.mark.parametrize("n", [2, 3, 4])
 def test_blend_passes_and_fused_blend(gpu, orc, dtype, tdtype, n):
