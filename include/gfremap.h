@@ -14,7 +14,7 @@
  *     gf_last_error() returns a thread-local message for the last failure on this thread.
  *   - Work is enqueued on the caller's hipStream_t (passed as void*; NULL = default stream) and is
  *     asynchronous.  Only gf_ctx_create/gf_ctx_destroy allocate or free device memory (two small constant tables
- *     and four 8 KB lens-table slots per context); the compute entry points neither allocate nor synchronise,
+ *     and four 16 KB lens-table slots per context); the compute entry points neither allocate nor synchronise,
  *     except the first call that sees a new lens D (see gf_frame_xform below).
  *   - Images are interleaved 3-channel (BGR/RGB order is irrelevant to the arithmetic), depth
  *     GF_DEPTH_U8 or GF_DEPTH_U16.  All image dimensions must be < 32767 (cv::remap's own assert).
@@ -65,7 +65,7 @@ GF_API int gf_ctx_destroy(void* ctx);
  * from (K, R, P) before its pixel loop: iR = (P[:, :3] * R)^-1, f/c = focal length/centre of K.  The lens distortion
  * coefficients D = (k1..k4) belong to the lens, not the frame: the calls below take them as 4 HOST doubles and keep a
  * per-context table of the radial scale function theta_d(atan r)/r for each distinct D (up to 4 lenses cached; the
- * first call with a new D builds the 8 KB table on the host, uploads it on the call's stream and waits for that
+ * first call with a new D builds the 16 KB table on the host, uploads it on the call's stream and waits for that
  * upload -- every later call is asynchronous). */
 typedef struct gf_frame_xform {
     double iR[9];
