@@ -8,7 +8,11 @@ from . import _lib, cv                                   # noqa: F401
 from .adaptive_zoom import AdaptiveZoom                  # noqa: F401
 from .calibrate_video import FisheyeCalibrator           # noqa: F401
 from .nonlinear_stretch import NonlinearStretch          # noqa: F401
-from .stabilizer import Stabilizer, ArraySource, ListSink, NullSink, synthetic_frames   # noqa: F401
+from .stabilizer import Stabilizer, OnlyUndistort, ArraySource, ListSink, NullSink, synthetic_frames   # noqa: F401
+from .frameio import RawVideoSource, RawVideoSink         # noqa: F401
+from .gyro_integrator import GyroIntegrator              # noqa: F401
+from .smoothing_algos import PlainSlerp                  # noqa: F401
 
-__all__ = ["cv", "FisheyeCalibrator", "NonlinearStretch", "Stabilizer", "ArraySource", "ListSink", "NullSink",
+__all__ = ["cv", "FisheyeCalibrator", "AdaptiveZoom", "NonlinearStretch", "Stabilizer", "OnlyUndistort", "ArraySource", "ListSink", "NullSink",
+           "RawVideoSource", "RawVideoSink", "GyroIntegrator", "PlainSlerp",
            "synthetic_frames"]

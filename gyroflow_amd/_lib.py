@@ -50,6 +50,10 @@ SIGNATURES = {
     "gf_blend_accumulate": [_vp, _i, _vp, _vp, _d, _i, _sz, _vp],
     "gf_blend_finalize": [_vp, _i, _vp, _vp, _sz, _vp],
     "gf_fisheye_undistort_points": [_vp, _vp, _sz, _dp, _dp, _vp, _sz, _vp, _vp],
+    "gf_host_integrate_gyro": [_dp, _sz, _dp, _dp],
+    "gf_host_interp_orientations": [_dp, _dp, _sz, _d, _d, _dp, _dp, _sz],
+    "gf_host_plain_slerp": [_dp, _sz, _d, _dp],
+    "gf_host_rot_between": [_dp, _dp, _sz, _dp],
     "gf_get_cubic_table": [_vp],
     "gf_lens_scale_host": [_dp, _dp, _sz, _dp],
 }
@@ -72,7 +76,8 @@ def load():
                 for name, args in SIGNATURES.items():
                     fn = getattr(lib, name)          # AttributeError if the symbol is not exported
                     fn.argtypes = args
-                    fn.restype = C.c_char_p if name == "gf_last_error" else C.c_int
+                    fn.restype = C.c_char_p if name == "gf_last_error" else \
+                        C.c_longlong if name == "gf_host_interp_orientations" else C.c_int
                 _lib = lib
     return _lib
 

@@ -312,3 +312,76 @@ class Stabilizer:
         sink.close()
         print("Render finished")
         return written[0]
+
+
+class OnlyUndistort:
+    """Lens undistortion without stabilisation: mirror of the reference's OnlyUndistort (stabilizer.py:1718-1844).
+
+    The reference builds static maps once (get_maps(fov_scale, new_img_dim=(w, h)), :1729), remaps every frame with
+    BORDER_CONSTANT (:1825) and crops the centre out_size window (:1792,1828).  Here the static transform is handed to the
+    fused kernel for every frame of a batch.  scale != 1 needs cv2.resize of the maps and the frame (:1800-1801,1823):
+    out of scope, rejected.  Deviation: the reference loops forever on a source that keeps failing; this stops when the
+    source is exhausted."""
+
+    def __init__(self, source, calibrationfile, width, height, fps, fov_scale=1.5, device=None):
+        self.undistort_fov_scale = fov_scale
+        self.cap = source
+        self.width, self.height, self.fps = int(width), int(height), fps
+        if isinstance(calibrationfile, FisheyeCalibrator):
+            self.undistort = calibrationfile
+        else:
+            self.undistort = FisheyeCalibrator()
+            self.undistort.load_calibration_json(calibrationfile, True)
+        self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        self.map1, self.map2 = self.undistort.get_maps(self.undistort_fov_scale, new_img_dim=(self.width, self.height),
+                                                       device=self.device)
+
+    def renderfile(self, starttime, stoptime, sink, out_size=(1920, 1080), scale=1, batch=8, pipeline_depth=2):
+        if scale != 1:
+            raise NotImplementedError("scale != 1 resizes the maps with cv2.resize(INTER_CUBIC): out of scope")
+        crop = (int(scale * (self.width - out_size[0]) / 2), int(scale * (self.height - out_size[1]) / 2))
+        if crop[0] < 0 or crop[1] < 0:
+            raise ValueError("out_size larger than the frame: numpy's negative slice start would wrap, as in the reference")
+        self.cap.set_pos(int(starttime * self.fps))
+        num_frames = int((stoptime - starttime) * self.fps)
+        map_h, map_w = int(self.map2.shape[0]), int(self.map2.shape[1])       # = calib_dimension (get_maps default output_dim)
+        xf1 = self.undistort.frame_xform(self.undistort_fov_scale, output_dim=None, new_img_dim=(self.width, self.height))
+        written = [0]
+
+        def emit(frames):
+            for f in frames:
+                sink.write(f[crop[1]:crop[1] + out_size[1] * scale, crop[0]:crop[0] + out_size[0] * scale])
+                written[0] += 1
+
+        pipe, pend, i = None, [], 0
+
+        def flush():
+            nonlocal pend
+            if not pend:
+                return
+            n = len(pend)
+            xf_dev = cv.xforms_to_device(np.tile(xf1, (n, 1)), self.device)
+            pipe.submit(pend, lambda din, dout: (cv.undistort_rotate(din, self.undistort.D, xf_dev, (map_w, map_h), dst=dout[:n],
+                                                                     borderMode=cv.BORDER_CONSTANT), n)[1])
+            pend = []
+
+        while True:
+            success, frame = self.cap.read()
+            if success:
+                i += 1
+            else:
+                break
+            if i > num_frames:
+                break
+            if pipe is None:
+                dtype = torch.uint8 if frame.dtype == np.uint8 else torch.uint16
+                pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (map_h, map_w), dtype, batch, emit,
+                                     depth=pipeline_depth)
+            pend.append(frame)
+            if len(pend) >= batch:
+                flush()
+        if pipe is not None:
+            flush()
+            pipe.flush()
+        sink.close()
+        return written[0]

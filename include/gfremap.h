@@ -157,6 +157,21 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
 GF_API int gf_fisheye_undistort_points(void* ctx, const double* pts, size_t n_pts, const double K_host[9], const double D_host[4],
                                        const double* PR, size_t n_sets, double* out, gf_stream_t stream);
 
+/* HOST (no GPU work): the sequential quaternion recurrences that produce the per-frame stabilisation quaternions, the
+ * hot path's other per-frame input.  They stay on the CPU; these entries only take the Python
+ * interpreter out of the per-sample loops.  Quaternions are (w,x,y,z) doubles; all pointers are host pointers.
+ *   gf_host_integrate_gyro       gyro_integrator.py:125-179 (GyroIntegrator.integrate_all, gyro only): gyro = n rows of
+ *                                [time s, wx, wy, wz rad/s]; out_q = n orientations starting from q0.
+ *   gf_host_interp_orientations  gyro_integrator.py:262-301 (get_interpolated_orientations): resamples at start + k*interval;
+ *                                returns the number of samples (call with NULL outputs to size the arrays), < 0 on error.
+ *   gf_host_plain_slerp          smoothing_algos.py:235-246 (PlainSlerp's forward + reverse exponential slerp), given alpha.
+ *   gf_host_rot_between          quaternion.py:83-87 row-wise: out[i] = inverse(q1[i]) * q2[i] (gyro_integrator.py:323-325). */
+GF_API int gf_host_integrate_gyro(const double* gyro_host, size_t n, const double q0_host[4], double* out_q_host);
+GF_API long long gf_host_interp_orientations(const double* times_host, const double* quats_host, size_t n, double start, double interval,
+                                             double* out_times_host, double* out_quats_host, size_t capacity);
+GF_API int gf_host_plain_slerp(const double* quats_host, size_t n, double alpha, double* out_host);
+GF_API int gf_host_rot_between(const double* q1_host, const double* q2_host, size_t n, double* out_host);
+
 /* HOST (no GPU work): the kernels' table approximation of the radial scale S(t) = theta_d(atan sqrt t)/sqrt t of
  * cv::fisheye::initUndistortRectifyMap, evaluated exactly as on the device, for n values t = x^2 + y^2 in [0, 255)
  * (NaN outside: there the kernels use the exact formula).  Lets CPU tests bound the table's error. */

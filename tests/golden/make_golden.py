@@ -201,7 +201,9 @@ def gen_quats():
                         K=np.array(cal["fisheye_params"]["camera_matrix"], np.float64),
                         D=np.array(cal["fisheye_params"]["distortion_coeffs"], np.float64),
                         calib_dimension=np.array([cal["calib_dimension"]["w"], cal["calib_dimension"]["h"]]),
-                        video_dim=np.array([g["video_info"]["orig_w"], g["video_info"]["orig_h"]]))
+                        video_dim=np.array([g["video_info"]["orig_w"], g["video_info"]["orig_h"]]),
+                        raw_imu=np.array(g["raw_imu"], np.float64),                     # t, gx, gy, gz, ax, ay, az (5 decimals)
+                        frame_orientation=np.array(g["frame_orientation"], np.float64))  # idx, t, w, x, y, z (full precision)
     print("gyroflow sample keys:", sorted(g.keys()))
 
 

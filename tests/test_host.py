@@ -132,7 +132,7 @@ def test_abi_exports_every_declared_symbol():
     """libgfremap.so loads without a GPU and exports exactly what include/gfremap.h declares."""
     with open(os.path.join(ROOT, "include", "gfremap.h")) as f:
         hdr = f.read()
-    declared = set(re.findall(r"GF_API\s+(?:const\s+char\*|int)\s+(gf_\w+)\s*\(", hdr))
+    declared = set(re.findall(r"GF_API\s+(?:const\s+char\*|int|long long)\s+(gf_\w+)\s*\(", hdr))
     assert len(declared) >= 15
     from gyroflow_amd import _lib
     lib = ctypes.CDLL(_lib.LIB_PATH)
@@ -245,3 +245,102 @@ def test_adaptive_zoom_host_math_matches_per_frame_restatement(orc):
     assert az.findFocalCenter((100, 3900, 50, 2950), (1920, 1080)) == (2000.0, 1500.0)
     a = np.arange(10.0)[::-1].copy()
     np.testing.assert_array_equal(az.min_rolling(a, 3), a[2:])
+
+
+def test_raw_video_adapters_roundtrip(tmp_path):
+    """frameio.RawVideoSource / RawVideoSink: headerless bgr24 / bgr48le files, cv2.VideoCapture-like positions."""
+    from gyroflow_amd import RawVideoSource, RawVideoSink, synthetic_frames
+    for dtype in (np.uint8, np.uint16):
+        frames = synthetic_frames(40, 24, n=5, dtype=dtype, seed=2)
+        path = str(tmp_path / ("clip_%s.raw" % np.dtype(dtype).name))
+        sink = RawVideoSink(path)
+        for f in frames:
+            sink.write(f)
+        sink.close()
+        assert sink.count == 5 and os.path.getsize(path) == 5 * 40 * 24 * 3 * np.dtype(dtype).itemsize
+        src = RawVideoSource(path, 40, 24, dtype)
+        assert src.count == 5
+        src.set_pos(2)
+        assert src.get_pos() == 2
+        ok, f = src.read()
+        assert ok and src.get_pos() == 3 and np.array_equal(f, frames[2])
+        buf = np.zeros((4, 24, 40, 3), dtype)
+        assert src.read_into(buf, 4) == 2 and np.array_equal(buf[1], frames[4])
+        ok, f = src.read()
+        assert not ok and f is None
+        src.release()
+    with pytest.raises(ValueError):
+        RawVideoSource(path, 4000, 3000, np.uint16)
+
+
+def test_quaternion_pipeline_reproduces_reference_capture():
+    """GyroIntegrator + PlainSlerp (host code in libgfremap) against the trace the reference's own gyro_integrator /
+    smoothing_algos produced for the FakeData('rollpitchyaw') gyro (tests/golden/make_golden.py)."""
+    from gyroflow_amd import GyroIntegrator, PlainSlerp
+    z = np.load(os.path.join(GOLDEN, "quats_rollpitchyaw.npz"))
+    g = GyroIntegrator(z["gyro"], zero_out_time=False, initial_orientation=z["initial_orientation"])
+    t_all, q_all = g.integrate_all()
+    assert q_all.shape == (1000, 4) and np.allclose(np.linalg.norm(q_all, axis=1), 1, atol=1e-15)
+    g.set_smoothing_algo(PlainSlerp())
+    t, s = g.get_interpolated_stab_transform(start=0, interval=1 / 30)
+    np.testing.assert_array_equal(t, z["times"])
+    np.testing.assert_allclose(s, z["stab_transform"], rtol=0, atol=1e-13)
+
+
+def test_quaternion_pipeline_reproduces_gyroflow_sample():
+    """Real data: raw_imu of plugins/blender/GX016015.MP4.gyroflow -> frame_orientation (stored at full precision) and
+    the stab_transform quaternions (stored to 5 decimals).  raw_imu itself is rounded to 5 decimals, hence ~1e-5."""
+    from scipy.spatial.transform import Rotation
+    from gyroflow_amd import GyroIntegrator
+    z = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
+    fps = float(z["fps"])
+    init = Rotation.from_euler('zxy', [0, 0, np.pi / 2]).as_quat()[[3, 0, 1, 2]]        # stabilizer.py:1690-1691
+    g = GyroIntegrator(z["raw_imu"][:, [0, 1, 2, 3]], zero_out_time=False, initial_orientation=init)
+    g.integrate_all()
+    t, o = g.get_interpolated_orientations(start=0, interval=1 / fps)
+    fo, st = z["frame_orientation"], z["stab_transform"]
+    assert len(t) == len(fo) == 1622
+    np.testing.assert_allclose(t, fo[:, 1], rtol=0, atol=1e-12)
+    assert np.abs(o - fo[:, 2:]).max() < 2e-5
+    _, s = g.get_interpolated_stab_transform(start=0, interval=1 / fps)
+    assert np.abs(s - st[:, 3:7]).max() < 2e-5
+
+
+def test_quaternion_host_code_matches_python_helpers():
+    """csrc/quat_host.cpp against gyroflow_amd/quaternion.py (numpy, the reference's formulas) on random data,
+    including the slerp branches (near-parallel, obtuse) and resampling with gaps / a negative start."""
+    from gyroflow_amd import GyroIntegrator, PlainSlerp, quaternion as quat
+    rng = np.random.default_rng(8)
+    n = 400
+    tt = np.cumsum(rng.uniform(0.002, 0.02, n)); tt[150:] += 0.4               # a gap in the gyro data
+    gyro = np.column_stack([tt, rng.normal(0, 3.0, (n, 3))])
+    gyro[20:30, 1:] = 0                                                        # samples without rotation
+    g = GyroIntegrator(gyro, zero_out_time=False)
+    _, q = g.integrate_all()
+    ori = np.array([1, 0.0001, 0.0001, 0.0001])
+    for i in range(n):
+        last = gyro[i - 1, 0] if i > 0 else gyro[i, 0]
+        nxt = gyro[i + 1, 0] if i < n - 1 else gyro[i, 0]
+        if np.any(gyro[i, 1:]):
+            ha = gyro[i, 1:] * ((nxt - last) / 2) * 0.5
+            l = np.sqrt(ha.dot(ha))
+            dq = quat.normalize(quat.quaternion(np.cos(l), *(ha * (np.sin(l) / l)))) if l > 1e-12 else quat.quaternion(1, 0, 0, 0)
+            ori = quat.normalize(quat.quaternion_multiply(ori, dq))
+        np.testing.assert_allclose(q[i], ori, rtol=0, atol=1e-14)
+    t, o = g.get_interpolated_orientations(start=-0.05, interval=1 / 60)
+    assert t[0] == -0.05 and np.all(o[t <= tt[0]] == q[0])
+    k = np.searchsorted(tt, t[200], side="right") - 1
+    w = (t[200] - tt[k]) / (tt[k + 1] - tt[k])
+    np.testing.assert_allclose(o[200], quat.single_slerp(q[k], q[k + 1], w), rtol=0, atol=1e-14)
+    ps = PlainSlerp(); ps.set_user_option("smoothness", 0.05)
+    _, sm = ps.get_smooth_orientations(t, o)
+    alpha = 1 - np.exp(-(1 / (len(t) / (t[-1] - t[0]))) / 0.05)
+    v = o[0]; fwd = []
+    for i in range(len(t)):
+        v = quat.single_slerp(v, o[i], alpha); fwd.append(v)
+    v = fwd[-1]; want = [None] * len(t)
+    for i in range(len(t) - 1, -1, -1):
+        v = quat.single_slerp(v, fwd[i], alpha); want[i] = v
+    np.testing.assert_allclose(sm, np.array(want), rtol=0, atol=1e-13)
+    far = quat.single_slerp([1, 0, 0, 0], [0, 1, 0, 0], 0.5)
+    np.testing.assert_allclose(far, [0.70710678, 0.70710678, 0, 0], atol=1e-8)      # SURVEY.md 8c verified value
