@@ -1576,19 +1576,12 @@ static int fused_checks(const char* fn, void* ctx, int depth, const void* src, i
     return GF_OK;
 }
 
-GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
-                           void* dst, int dw, int dh, size_t dstep, size_t dframe,
-                           const double D[4], const gf_frame_xform* xf_dev, int n_frames, int border, const double bv[4], gf_stream_t stream)
+static int launch_fused(Ctx* c, bool lds_tiles, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                        void* dst, int dw, int dh, size_t dstep, size_t dframe, const double* lens, LensK lk,
+                        const gf_frame_xform* xf_dev, int n_frames, int border, const double* bv, hipStream_t stream)
 {
-    int rc = fused_checks("gf_undistort_rotate_c3", ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_frames, n_frames, border);
-    if (rc) return rc;
-    Ctx* c = (Ctx*)ctx;
-    DeviceGuard dg(c->device);
-    const double* lens; LensK lk;
-    rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
-    const bool aligned16 = ((uintptr_t)src & 15) == 0 && (sstep & 15) == 0 && (sframe & 15) == 0;
-    if (aligned16 && g_use_lds_tiles) {               // LDS-staged source taps
+    if (lds_tiles) {               // LDS-staged source taps
         const int npass = depth == GF_DEPTH_U8 ? 2 : 1;
         A.tiles_x = (dw + LT_W - 1)/LT_W; A.tiles_y = (dh + LT_RPP*npass - 1)/(LT_RPP*npass);
         const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
@@ -1598,7 +1591,7 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
         if (blocks == 0) blocks = NXCD;
         if (blocks > n_work) blocks = (unsigned)n_work;
         dim3 grid(blocks, 1);
-#define LAUNCH_LDS(DEPTH_, BORDER_, NP_) hipLaunchKernelGGL((k_undistort_rotate_lds<DEPTH_, BORDER_, NP_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work)
+#define LAUNCH_LDS(DEPTH_, BORDER_, NP_) hipLaunchKernelGGL((k_undistort_rotate_lds<DEPTH_, BORDER_, NP_>), grid, dim3(BLOCK), 0, stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work)
         if (depth == GF_DEPTH_U8) {
             if (border == GF_BORDER_CONSTANT) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_CONSTANT, 2);
             else if (border == GF_BORDER_REPLICATE) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_REPLICATE, 2);
@@ -1618,10 +1611,26 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
         if (blocks == 0) blocks = NXCD;
         if (blocks > n_work) blocks = (unsigned)n_work;          // n_work is a multiple of 8
         dim3 grid(blocks, 1);
-        DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work);
+        DISPATCH_DEPTH_BORDER(k_undistort_rotate, depth, border, grid, stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work);
     }
     HIP_TRY(hipGetLastError());
     return GF_OK;
+}
+
+
+GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                           void* dst, int dw, int dh, size_t dstep, size_t dframe,
+                           const double D[4], const gf_frame_xform* xf_dev, int n_frames, int border, const double bv[4], gf_stream_t stream)
+{
+    int rc = fused_checks("gf_undistort_rotate_c3", ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_frames, n_frames, border);
+    if (rc) return rc;
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    const double* lens; LensK lk;
+    rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
+    const bool aligned16 = ((uintptr_t)src & 15) == 0 && (sstep & 15) == 0 && (sframe & 15) == 0;
+    return launch_fused(c, aligned16 && g_use_lds_tiles, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
+                        border, bv, (hipStream_t)stream);
 }
 
 GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
