@@ -100,6 +100,25 @@ class FisheyeCalibrator:
             raise KeyError("Error loading preset file")
         return self.extra_cam_info
 
+    def get_calibration_data(self):
+        """Preset dictionary in the reference's format (calibrate_video.py:483-518)."""
+        info = getattr(self, "extra_cam_info", {}) or {}
+        return {
+            "name": info.get("name", ""), "note": info.get("note", ""), "calibrated_by": info.get("calibrated_by", "N/A"),
+            "camera_brand": info.get("camera_brand", "N/A"), "camera_model": info.get("camera_model", "N/A"),
+            "lens_model": info.get("lens_model", "N/A"), "camera_setting": info.get("camera_setting", "N/A"),
+            "calibrator_version": info.get("calibrator_version", "N/A"), "date": info.get("date", "N/A"),
+            "calib_dimension": {"w": self.calib_dimension[0], "h": self.calib_dimension[1]},
+            "orig_dimension": {"w": self.orig_dimension[0], "h": self.orig_dimension[1]},
+            "input_horizontal_stretch": self.input_horizontal_stretch,
+            "num_images": self.num_images_used,
+            "use_opencv_fisheye": True,
+            "fisheye_params": {"RMS_error": self.RMS_error, "camera_matrix": np.asarray(self.K).tolist(),
+                               "distortion_coeffs": np.asarray(self.D).flatten().tolist()},
+            "use_opencv_standard": False,
+            "calib_params": {},
+        }
+
     def load_calibration_json(self, filename, printinfo=False):
         with open(filename, "r") as infile:
             presets = json.load(infile)

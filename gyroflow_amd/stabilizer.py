@@ -120,7 +120,11 @@ class Stabilizer:
         else:
             self.undistort = FisheyeCalibrator()
             self.undistort.load_calibration_json(calibration)
-        self.stab_transform = np.asarray(stab_transform, np.float64)
+        self.stab_transform = None if stab_transform is None else np.asarray(stab_transform, np.float64)
+        self.times = None
+        self.new_integrator = self.integrator = None
+        self.smoothing_algo = None
+        self.gyro_data = self.acc_data = None
         self.fps = fps
         self.width, self.height = int(width), int(height)
         self.orig_dimension = (self.width, self.height)
@@ -133,6 +137,83 @@ class Stabilizer:
         else:       # no GPU: only the host-side logic (schedule(), border selection) is usable
             self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
         self.adaptive_zoom = None          # optional override: (stab_transform, out_size, fps, smoothingFocus, tstart, tend) -> (fcorr, focalCenter)
+
+    # ------------------------------------------------------------------ quaternion producer + .gyroflow data files
+    def set_smoothing_algo(self, algo=None):
+        from .smoothing_algos import PlainSlerp
+        self.smoothing_algo = algo if algo else PlainSlerp()
+
+    def update_smoothing(self):
+        """reference :256-267: integrate, smooth, resample at the frame rate -> self.times, self.stab_transform."""
+        if getattr(self, "new_integrator", None) is not None:
+            if getattr(self, "smoothing_algo", None) is None:
+                self.set_smoothing_algo()
+            self.new_integrator.integrate_all(use_acc=False)
+            self.new_integrator.set_smoothing_algo(self.smoothing_algo)
+            self.times, self.stab_transform = self.new_integrator.get_interpolated_stab_transform(start=0, interval=1 / self.fps)
+            return True
+        print("Orientations not calculated yet")
+        return False
+
+    def import_gyroflow_file(self, filename="file.gyroflow"):
+        """reference :1676-1712: calibration + raw IMU from a Gyroflow data file; orientations are integrated from the
+        gyro columns (the accelerometer columns are kept but unused: use_acc=False as in the reference's import)."""
+        import json
+        from scipy.spatial.transform import Rotation
+        from .gyro_integrator import GyroIntegrator
+        print("Loading Gyroflow data file")
+        with open(filename, "r") as infile:
+            try:
+                gyroflow_data = json.load(infile)
+                self.undistort.load_calibration_data(gyroflow_data["calibration_data"], True)
+                self.video_rotate_code = gyroflow_data["video_rotate_code"]
+                initial_orientation = Rotation.from_euler('zxy', [0, 0, np.pi / 2]).as_quat()
+                initial_orientation[[0, 1, 2, 3]] = initial_orientation[[3, 0, 1, 2]]
+                raw_imu = np.array(gyroflow_data["raw_imu"])
+                self.gyro_data = raw_imu[:, [0, 1, 2, 3]]
+                self.acc_data = raw_imu[:, [0, 4, 5, 6]] if gyroflow_data["sensor_DOF"] >= 6 else None
+                self.integrator = GyroIntegrator(self.gyro_data, zero_out_time=False, initial_orientation=initial_orientation,
+                                                 acc_data=self.acc_data)
+                self.new_integrator = self.integrator
+                self.new_integrator.integrate_all(use_acc=False)
+                self.use_gyroflow_data_file = True
+            except KeyError:
+                print("Couldn't load gyroflow data file")
+                return False
+        return True
+
+    def export_gyroflow_file(self, filename, out_size=(1920, 1080), smoothingFocus=2.0, videofile=""):
+        """reference :1574-1672: the per-frame data plugins consume: [index, time, fcorr, w, x, y, z] rows rounded to 5
+        decimals, min_fcorr, frame orientations, raw IMU and the calibration."""
+        import json
+        from datetime import date
+        integ = getattr(self, "new_integrator", None)
+        if integ is None or self.stab_transform is None:
+            print("Unable to export a data file")
+            return False
+        data = {"title": "Gyroflow data file", "videofile": videofile,
+                "calibration_data": self.undistort.get_calibration_data(),
+                "video_rotate_code": getattr(self, "video_rotate_code", -1), "gyro_lpf_cutoff": getattr(self, "gyro_lpf_cutoff", -1),
+                "date": str(date.today()),
+                "video_info": {"orig_w": self.orig_dimension[0], "orig_h": self.orig_dimension[1], "process_w": self.width,
+                               "process_h": self.width, "fps": self.fps, "num_frames": getattr(self.cap, "count", len(self.stab_transform))},
+                "sensor_DOF": 6 if getattr(self, "acc_data", None) is not None else 3}
+        raw = integ.gyro[:, :4] if getattr(self, "acc_data", None) is None else np.column_stack([integ.gyro[:, :4], self.acc_data[:, 1:4]])
+        data["raw_imu"] = np.round(raw, 5).tolist()
+        data["stab_summary"] = self.smoothing_algo.get_summary()
+        t, o = integ.get_interpolated_orientations(start=0, interval=1 / self.fps)
+        data["frame_orientation"] = np.hstack([np.arange(o.shape[0])[..., None], np.array(t)[..., None], o]).tolist()
+        data["frame_orientation_filtered"] = []
+        stab = np.array(self.stab_transform)
+        fcorr, _ = AdaptiveZoom(fisheyeCalibrator=self.undistort, device=self.device).compute(
+            quaternions=self.stab_transform, output_dim=out_size, fps=self.fps, smoothingFocus=smoothingFocus)
+        data["min_fcorr"] = float(np.min(fcorr))
+        rows = np.hstack([np.arange(stab.shape[0])[..., None], np.array(self.times)[..., None], np.asarray(fcorr, np.float64)[..., None], stab])
+        data["stab_transform"] = np.round(rows, 5).tolist()
+        with open(filename, 'w') as outfile:
+            json.dump(data, outfile, indent=1, separators=(',', ': '))
+        print("Finished exporting")
+        return True
 
     def set_hyperlapse(self, hyperlapse_multiplier=1, hyperlapse_num_blended_frames=1):
         # frames |0|1|2|3|4|5|6|7|...  mult=4, num_blend=2  ->  |0+1|4+5|...

@@ -151,3 +151,50 @@ def test_only_undistort_renderfile(gpu, orc, tmp_path):
         np.testing.assert_array_equal(f, want)
     with pytest.raises(NotImplementedError):
         ou.renderfile(0, 1, RawVideoSink(dst_path), out_size=out_size, scale=2)
+
+
+def test_gyroflow_data_file_roundtrip(gpu, tmp_path):
+    """import_gyroflow_file -> update_smoothing -> export_gyroflow_file (stabilizer.py:256-267,1574-1712) on a data file
+    rebuilt from the fixture of plugins/blender/GX016015.MP4.gyroflow: the exported per-frame rows reproduce the ones the
+    reference wrote (quaternions and fcorr to the file's 5 decimals, given that raw_imu is itself rounded)."""
+    import json
+    import os
+    from conftest import GOLDEN
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, synthetic_frames
+    z = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
+    cal0 = FisheyeCalibrator()
+    cal0.load_calibration_json(preset_path("hero9_4k_43"))
+    caldata = cal0.get_calibration_data()
+    caldata["fisheye_params"]["camera_matrix"] = z["K"].tolist()
+    caldata["fisheye_params"]["distortion_coeffs"] = z["D"].tolist()
+    src_file = str(tmp_path / "in.gyroflow")
+    with open(src_file, "w") as f:
+        json.dump({"title": "Gyroflow data file", "calibration_data": caldata, "video_rotate_code": -1, "sensor_DOF": 6,
+                   "raw_imu": z["raw_imu"].tolist()}, f)
+    fps = float(z["fps"])
+    st = Stabilizer(ArraySource(synthetic_frames(64, 48, n=2)), cal0, None, fps, 2704, 2028, device=gpu)
+    assert not st.update_smoothing()
+    assert st.import_gyroflow_file(src_file)
+    assert np.array_equal(st.undistort.K, z["K"]) and st.acc_data.shape == (len(z["raw_imu"]), 4)
+    assert st.update_smoothing()
+    ref = z["stab_transform"]
+    assert st.stab_transform.shape == (1622, 4) and np.abs(st.stab_transform - ref[:, 3:7]).max() < 2e-5
+    out_file = str(tmp_path / "out.gyroflow")
+    assert st.export_gyroflow_file(out_file, out_size=(1920, 1080), smoothingFocus=2.0, videofile="GX016015.MP4")
+    with open(out_file) as f:
+        g = json.load(f)
+    rows = np.array(g["stab_transform"])
+    assert rows.shape == ref.shape
+    np.testing.assert_array_equal(rows[:, 0], ref[:, 0])
+    assert np.abs(rows[:, 1] - ref[:, 1]).max() <= 1e-5
+    assert np.abs(rows[:, 2] - ref[:, 2]).max() < 2e-4 and abs(g["min_fcorr"] - float(z["min_fcorr"])) < 1e-4
+    assert np.abs(rows[:, 3:7] - ref[:, 3:7]).max() < 3e-5
+    assert g["stab_summary"] == "Plain 3D smoothing,smoothness:0.2" and g["sensor_DOF"] == 6
+    assert np.abs(np.array(g["frame_orientation"])[:, 2:] - z["frame_orientation"][:, 2:]).max() < 2e-5
+    # the exported file loads again
+    st2 = Stabilizer(ArraySource(synthetic_frames(64, 48, n=2)), cal0, None, fps, 2704, 2028, device=gpu)
+    assert st2.import_gyroflow_file(out_file) and st2.update_smoothing()
+    assert np.abs(st2.stab_transform - st.stab_transform).max() < 2e-5
+    with open(str(tmp_path / "bad.gyroflow"), "w") as f:
+        json.dump({"title": "x"}, f)
+    assert st2.import_gyroflow_file(str(tmp_path / "bad.gyroflow")) is False
