@@ -337,3 +337,39 @@ def test_error_codes(gpu):
         _lib.make_frame_xform(np.eye(3), np.zeros((3, 3)), np.eye(3))
     with pytest.raises(TypeError):
         cv.remap(torch.zeros((4, 4, 3), dtype=torch.float32, device=gpu), m1[:4, :4], m2[:4, :4], cv.INTER_LINEAR)
+
+
+def test_two_threads_two_streams_two_lenses(gpu, orc):
+    """get_maps is called from the render thread and the preview thread on one calibrator (gyroflow.py:282):
+    two Python threads, each on its own HIP stream and with its own lens (two slots of the context's lens cache), must
+    produce what they produce alone."""
+    import threading
+    from gyroflow_amd import cv, FisheyeCalibrator, synthetic_frames
+    from conftest import preset_path
+    jobs = []
+    for k, (preset, (w, h), (ow, oh)) in enumerate([("hero7_4k_169", (960, 540), (640, 360)), ("hero8_27k_43", (676, 507), (480, 270))]):
+        cal = FisheyeCalibrator(); cal.load_calibration_json(preset_path(preset))
+        frames = torch.from_numpy(np.stack(synthetic_frames(w, h, n=4, seed=k))).to(gpu)
+        q = np.array([[0.999, 0.02 * (k + 1), -0.03, 0.01 * i] for i in range(4)]); q /= np.linalg.norm(q, axis=1)[:, None]
+        xf = cv.xforms_to_device(cal.frame_xforms(0.9, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
+        alone = cv.undistort_rotate(frames, cal.D, xf, (ow, oh)).clone()
+        m_alone = [t.clone() for t in cal.get_maps(0.9, new_img_dim=(w, h), output_dim=(ow, oh), update_new_K=False, quat=q[1], device=gpu)]
+        jobs.append(dict(cal=cal, frames=frames, xf=xf, out=(ow, oh), dim=(w, h), q=q, alone=alone, m_alone=m_alone, bad=0))
+    torch.cuda.synchronize()
+
+    def work(j):
+        s = torch.cuda.Stream(gpu)
+        with torch.cuda.stream(s):
+            for _ in range(25):
+                got = cv.undistort_rotate(j["frames"], j["cal"].D, j["xf"], j["out"])
+                m = j["cal"].get_maps(0.9, new_img_dim=j["dim"], output_dim=j["out"], update_new_K=False, quat=j["q"][1], device=gpu)
+                s.synchronize()
+                if not (torch.equal(got, j["alone"]) and torch.equal(m[0], j["m_alone"][0]) and torch.equal(m[1], j["m_alone"][1])):
+                    j["bad"] += 1
+
+    th = [threading.Thread(target=work, args=(j,)) for j in jobs]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert [j["bad"] for j in jobs] == [0, 0]
