@@ -48,42 +48,93 @@ __global__ void __launch_bounds__(256) k_gather(const uint8_t* __restrict__ base
 // Streaming variant (cold lines): a wave walks down an image-like region; per "pass" it issues 8 loads the way the fused
 // kernel does for 4 pixels x 2 source rows.  layout 0: a lane owns 4 adjacent pixels (lane stride 12 B, the 4 loads of a
 // row are 3 B apart); layout 1: adjacent lanes own adjacent pixels (lane stride 3 B, the 4 loads of a row are 192 B apart).
+// mode bits: 1 = a wave covers two output rows (lanes 32..63 one row further down), 2 = sloped rows (the source row
+// advances by one every 16 pixels, like a 3.6 degree roll), 4 = one 12-byte store per lane and pass, 8 = odd-byte alignment
 template <int W>
-__global__ void __launch_bounds__(256) k_stream(const uint8_t* __restrict__ base, uint32_t* out, int layout, int rowstep, int rows, size_t region)
+__global__ void __launch_bounds__(256) k_stream(const uint8_t* __restrict__ base, uint32_t* out, int layout, int rowstep, int rows, size_t region, int mode,
+                                                uint8_t* __restrict__ sink)
 {
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t acc = 0;
-    // each block owns a 768-byte wide column strip; its 4 waves take rows y = wave, wave + 4, ...
-    size_t col = ((size_t)blockIdx.x*768u) % (size_t)(rowstep - 1024);
-    size_t strip = ((size_t)blockIdx.x*768u) / (size_t)(rowstep - 1024);
-    const uint8_t* p0 = base + (strip*(size_t)rows*rowstep) % region + col;
+    size_t col = ((size_t)blockIdx.x*768u) % (size_t)(rowstep - 2048);
+    size_t strip = ((size_t)blockIdx.x*768u) / (size_t)(rowstep - 2048);
+    const uint8_t* p0 = base + (strip*(size_t)(rows + 80)*rowstep) % region + col;
+    const unsigned l2 = (mode & 1) ? (lane & 31) : lane;
+    const unsigned rowsel = (mode & 1) ? (lane >> 5) : 0;
     for (int y = wave; y < rows; y += 4) {
-        const uint8_t* r0 = p0 + (size_t)y*rowstep;
+        const uint8_t* r0 = p0 + (size_t)((mode & 1) ? 2*y + (int)rowsel : y)*rowstep;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const unsigned o = layout == 0 ? lane*12u + i*3u : lane*3u + i*192u;
+            const unsigned px = layout == 0 ? l2*4u + i : l2 + i*64u;
+            unsigned o = px*3u + ((mode & 8) ? 1u : 0u);
+            if (mode & 2) o += (px >> 4)*(unsigned)rowstep;
             acc ^= ld<W>(r0 + o);
             acc ^= ld<W>(r0 + rowstep + o);
+        }
+        if (mode & 4) {
+            struct alignas(4) W3 { uint32_t a, b, c; };
+            *(W3*)(sink + ((size_t)blockIdx.x*rows + y)*768u*2 + lane*12u) = W3{acc, acc + 1, acc + 2};
         }
     }
     out[blockIdx.x*256 + threadIdx.x] = acc;
 }
 
 template <int W>
-static void run_stream(const uint8_t* buf, uint32_t* out, int layout, int rowstep, size_t region)
+static void run_stream(const uint8_t* buf, uint32_t* out, int layout, int rowstep, size_t region, int mode = 0, uint8_t* sink = nullptr)
 {
-    const int rows = 512, blocks = 256*8;
+    const int rows = 256, blocks = 256*8;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    hipLaunchKernelGGL(k_stream<W>, dim3(blocks), dim3(256), 0, 0, buf, out, layout, rowstep, 8, region);
+    hipLaunchKernelGGL(k_stream<W>, dim3(blocks), dim3(256), 0, 0, buf, out, layout, rowstep, 8, region, mode, sink);
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(e0));
-    hipLaunchKernelGGL(k_stream<W>, dim3(blocks), dim3(256), 0, 0, buf, out, layout, rowstep, rows, region);
+    hipLaunchKernelGGL(k_stream<W>, dim3(blocks), dim3(256), 0, 0, buf, out, layout, rowstep, rows, region, mode, sink);
     CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     const double instr_per_cu = (double)blocks*rows*8/256.0;
     const double ns = ms*1e6/instr_per_cu;
-    printf("  stream layout %d width %2d B: %6.2f ns = %5.1f cycles (2.4 GHz) per wave-instr per CU; %.0f GB/s of distinct bytes\n", layout, W, ns, ns*2.4,
-           (double)blocks*rows*768.0/(ms*1e-3)/1e9);
+    printf("  stream layout %d mode %2d width %2d B: %6.2f ns per wave-load per CU (= %5.1f cycles at 2.1 GHz)\n", layout, mode, W, ns, ns*2.1);
+}
+
+// Store cost: every lane writes W contiguous bytes (lane stride W), rows of 64*W bytes; NT = nontemporal hint.
+template <int N> struct alignas(4) SW { uint32_t v[N]; };
+template <int W, int NT>
+__global__ void __launch_bounds__(256) k_store(uint8_t* __restrict__ sink, int iters, uint32_t* out)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v = lane*2654435761u;
+    uint8_t* p = sink + ((size_t)blockIdx.x*4 + wave)*(size_t)iters*64*W + lane*W;      // host checks the extent
+    for (int it = 0; it < iters; it++) {
+        uint32_t* q = (uint32_t*)(p + (size_t)it*64*W);
+        if (NT) {
+#pragma unroll
+            for (int k = 0; k < W/4; k++) __builtin_nontemporal_store(v + k, q + k);
+        } else {
+            SW<W/4> x;
+#pragma unroll
+            for (int k = 0; k < W/4; k++) x.v[k] = v + k;
+            *(SW<W/4>*)q = x;
+        }
+        v = v*3 + 1;
+    }
+    out[blockIdx.x*256 + threadIdx.x] = v;
+}
+
+template <int W, int NT>
+static void run_store(uint8_t* sink, size_t sink_bytes, uint32_t* out)
+{
+    const int iters = 256, blocks = 256*8;
+    if ((size_t)blocks*4*iters*64*W > sink_bytes) { printf("  store width %d: sink too small, skipped\n", W); return; }
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_store<W, NT>), dim3(blocks), dim3(256), 0, 0, sink, 8, out);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_store<W, NT>), dim3(blocks), dim3(256), 0, 0, sink, iters, out);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr_per_cu = (double)blocks*4*iters/256.0;
+    const double ns = ms*1e6/instr_per_cu;
+    printf("  store width %2d B%s: %6.2f ns per wave-store per CU (= %5.1f cycles at 2.1 GHz, %5.1f B/clk/CU, %.0f GB/s)\n", W, NT ? " nontemporal" : "            ",
+           ns, ns*2.1, 64.0*W/(ns*2.1), (double)blocks*4*iters*64.0*W/(ms*1e-3)/1e9);
 }
 
 template <int W>
@@ -123,7 +174,14 @@ int main()
         const size_t big = (size_t)1 << 31;
         uint8_t* b2; CK(hipMalloc(&b2, big + (1 << 24))); CK(hipMemset(b2, 1, big + (1 << 24)));
         printf("streaming (cold) gathers, 4 px x 2 rows per lane and pass\n");
-        for (int layout = 0; layout < 2; layout++) { run_stream<4>(b2, out, layout, rowstep, big); run_stream<8>(b2, out, layout, rowstep, big); }
+        const size_t sink_bytes = ((size_t)1 << 31) + 65536;       // k_stream mode 4 needs 2048*256*1536 = 805 MB, k_store up to 2 GiB
+        uint8_t* sink; CK(hipMalloc(&sink, sink_bytes));
+        for (int mode : {0, 1, 2, 3, 4, 8, 7, 15}) run_stream<8>(b2, out, 0, rowstep, big, mode, sink);
+        run_stream<8>(b2, out, 1, rowstep, big, 0, sink);
+        printf("streaming stores\n");
+        run_store<4, 0>(sink, sink_bytes, out); run_store<8, 0>(sink, sink_bytes, out); run_store<12, 0>(sink, sink_bytes, out); run_store<16, 0>(sink, sink_bytes, out);
+        run_store<4, 1>(sink, sink_bytes, out); run_store<8, 1>(sink, sink_bytes, out); run_store<12, 1>(sink, sink_bytes, out); run_store<16, 1>(sink, sink_bytes, out);
+        CK(hipFree(sink));
         CK(hipFree(b2));
     }
     printf("partial exec masks, width 8, lane stride 12\n");
