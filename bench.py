@@ -167,7 +167,7 @@ def main():
         if world == 1:
             n_cpu = args.cpu_frames
             if n_cpu < 0:
-                n_cpu = {"c1": 120, "c2": 120, "c3": 32, "c5": 12}[args.config]
+                n_cpu = {"c1": 400, "c2": 400, "c3": 96, "c5": 36}[args.config]      # about 10 s of CPU work
             if n_cpu > 0:
                 threads = min(16, os.cpu_count() or 1)
                 out["cpu_baseline"] = cpu_baseline(args.config, cal, quats, ring, n_cpu, threads)

@@ -237,7 +237,7 @@ struct Xf {                // kernel-side copy of gf_frame_xform
     double iR[9];
     double f[2], c[2];
 };
-struct LensK { double k[4]; };
+struct LensK { double k[4]; double bound; };      // bound >= |theta_d| wherever the lens table applies (t < 255)
 
 // Exact per-pixel body of cv::fisheye::initUndistortRectifyMap: 32*u, 32*v from the homogeneous ray (_x,_y,_w).
 // Used where the table does not apply.  Never inlined: it is the cold path.
@@ -313,19 +313,41 @@ __device__ __forceinline__ void coord_fast(const RowC& r, const double2* __restr
     tv = __fma_rn(y*S, r.fy32, r.cy32);
 }
 
-__device__ __forceinline__ bool lens_ok(double W, unsigned qhi) { return qhi < LENS_HI_LIMIT && W > 0; }   // q >= 1 unless NaN
+__device__ __forceinline__ bool lens_ok(double W, unsigned qhi, unsigned hi_limit) { return qhi < hi_limit && W > 0; }   // q >= 1 unless NaN
+
+// The table path rounds with the 1.5*2^52 trick, which needs |32 u|, |32 v| < 2^31; u = f*(x S) + c with |x S| = |theta_d| <=
+// lk.bound.  For a frame whose focal length or principal point is absurd (or NaN) the limit comes back 0: every pixel then
+// takes the exact formula and cvRound's overflow rule (INT_MIN), like the reference.  Uniform per frame.
+__device__ __forceinline__ unsigned lens_hi_limit(const Xf& xf, const LensK& lk)
+{
+    const double mu = fabs(xf.f[0])*lk.bound + fabs(xf.c[0]), mv = fabs(xf.f[1])*lk.bound + fabs(xf.c[1]);
+    // a non-finite column step makes column 0 special (the reference adds the step j times: zero times there), see ray_cold
+    const double step0 = xf.iR[0]*0.0 + xf.iR[3]*0.0 + xf.iR[6]*0.0;             // 0, or NaN if any step is inf/NaN
+    return (mu < 16777216.0 && mv < 16777216.0 && step0 == 0.0) ? LENS_HI_LIMIT : 0u;           // 2^24 px: 32*u stays below 2^29
+}
+
+// The homogeneous ray of column j for the cold path: column 0 is the row start itself (the reference's loop has not yet
+// added the column step), which matters when the step is inf/NaN (0*inf != 0).
+__device__ __forceinline__ void ray_cold(const RowC& r, int j, double& X, double& Y, double& W)
+{
+    const double dj = (double)j;
+    X = j == 0 ? r.rx : __fma_rn(dj, r.ax, r.rx);
+    Y = j == 0 ? r.ry : __fma_rn(dj, r.ay, r.ry);
+    W = j == 0 ? r.rw : __fma_rn(dj, r.aw, r.rw);
+}
 
 // Q5 integers of one pixel, fast or exact.
-__device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const LensK& lk, const double2* __restrict__ tab, int j,
+__device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const LensK& lk, unsigned hi_limit, const double2* __restrict__ tab, int j,
                                          int& iu, int& iv)
 {
     double X, Y, W, tu, tv;
     unsigned qhi;
     coord_fast(r, tab, j, X, Y, W, qhi, tu, tv);
-    if (lens_ok(W, qhi)) {
+    if (lens_ok(W, qhi, hi_limit)) {
         iu = __double2loint(tu + ROUND_MAGIC);
         iv = __double2loint(tv + ROUND_MAGIC);
     } else {
+        ray_cold(r, j, X, Y, W);
         const double2 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
         iu = cv_round_d(o.x); iv = cv_round_d(o.y);
     }
@@ -334,7 +356,7 @@ __device__ __forceinline__ void coord_q5(const RowC& r, const Xf& xf, const Lens
 // Q5 integers of PXT adjacent pixels: the table path for all of them in straight-line code (independent chains
 // interleave), one combined validity test (W is linear in j, so its sign is decided at the two ends; the largest high
 // dword decides the range), then the exact formula for the rare pixels that need it.
-__device__ __forceinline__ void coord_q5x4(const RowC& r, const Xf& xf, const LensK& lk, const double2* __restrict__ tab, int j0,
+__device__ __forceinline__ void coord_q5x4(const RowC& r, const Xf& xf, const LensK& lk, unsigned hi_limit, const double2* __restrict__ tab, int j0,
                                            int* iu, int* iv)
 {
     unsigned qhi[PXT];
@@ -351,13 +373,13 @@ __device__ __forceinline__ void coord_q5x4(const RowC& r, const Xf& xf, const Le
     }
     static_assert(PXT == 4, "combined validity test is written for 4 pixels");
     const unsigned qmax = max(max(qhi[0], qhi[1]), max(qhi[2], qhi[3]));
-    const bool all_ok = qmax < LENS_HI_LIMIT && fmin(Wj[0], Wj[PXT - 1]) > 0;
+    const bool all_ok = qmax < hi_limit && fmin(Wj[0], Wj[PXT - 1]) > 0;
     if (!all_ok) {
 #pragma unroll
         for (int i = 0; i < PXT; i++)
-            if (!lens_ok(Wj[i], qhi[i])) {
-                const double dj = (double)(j0 + i);
-                const double X = __fma_rn(dj, r.ax, r.rx), Y = __fma_rn(dj, r.ay, r.ry), W = __fma_rn(dj, r.aw, r.rw);
+            if (!lens_ok(Wj[i], qhi[i], hi_limit)) {
+                double X, Y, W;
+                ray_cold(r, j0 + i, X, Y, W);
                 const double2 o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
                 iu[i] = cv_round_d(o.x); iv[i] = cv_round_d(o.y);
             }
@@ -806,6 +828,7 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
         const int x0 = tx*TILE_W + lx*PXT;
         if (x0 >= A.dw) continue;
         const Xf& xf = xfs[frame];
+        const unsigned hi_limit = lens_hi_limit(xf, lk);
         const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
 #if GF_K1_PIPELINE
         // Software pipeline over the tile's passes: the taps of row y are in flight while the coordinates of row
@@ -813,7 +836,7 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
         int y = ty*TILE_H + ly;
         if (y >= A.dh) continue;
         int iu[PXT], iv[PXT];
-        coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu, iv);
+        coord_q5x4(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, iu, iv);
 #pragma unroll 1
         for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
             typename TapsT<DEPTH>::T T[PXT];
@@ -821,7 +844,7 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
             const int yn = y + PASS_H;
             const bool more = pass + 1 < TILE_H/PASS_H && yn < A.dh;
             int nu[PXT], nv[PXT];
-            if (more) coord_q5x4(row_consts(xf, yn), xf, lk, s_tab, x0, nu, nv);
+            if (more) coord_q5x4(row_consts(xf, yn), xf, lk, hi_limit, s_tab, x0, nu, nv);
             int px[PXT][3];
             const unsigned keep = finish4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, interior, T, px);
             uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
@@ -837,7 +860,7 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
             const int y = ty*TILE_H + pass*PASS_H + ly;
             if (y >= A.dh) break;
             int iu[PXT], iv[PXT];
-            coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu, iv);
+            coord_q5x4(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, iu, iv);
             int px[PXT][3];
             const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
             uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
@@ -885,6 +908,7 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, con
         if (!tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) continue;     // uniform
         const int x0 = tx*LT_W + lx*PXT;
         const Xf& xf = xfs[frame];
+        const unsigned hi_limit = lens_hi_limit(xf, lk);
         const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
 
         __syncthreads();                             // the previous tile's LDS taps and s_box are no longer read
@@ -895,7 +919,7 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, con
             const int kx = k % 3, ky = k / 3;
             const int px_ = kx == 0 ? xa : kx == 1 ? (xa + xb) >> 1 : xb, py_ = ky == 0 ? ya : ky == 1 ? (ya + yb) >> 1 : yb;
             int su, sv;
-            coord_q5(row_consts(xf, py_), xf, lk, s_tab, px_, su, sv);
+            coord_q5(row_consts(xf, py_), xf, lk, hi_limit, s_tab, px_, su, sv);
             su >>= INTER_BITS; sv >>= INTER_BITS;
             atomicMin(&s_box[0], su); atomicMax(&s_box[1], su); atomicMin(&s_box[2], sv); atomicMax(&s_box[3], sv);
         }
@@ -905,7 +929,7 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, con
         for (int p = 0; p < NPASS; p++) {
             const int y = ty*LT_H + p*LT_RPP + ly;
             if (x0 < A.dw && y < A.dh) {
-                coord_q5x4(row_consts(xf, y), xf, lk, s_tab, x0, iu[p], iv[p]);
+                coord_q5x4(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, iu[p], iv[p]);
             } else {
 #pragma unroll
                 for (int i = 0; i < PXT; i++) iu[p][i] = iv[p][i] = 0;
@@ -995,10 +1019,11 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, c
         for (int b = 0; b < n_blend; b++) {
             const int frame = g*frames_per_group + b;
             const Xf& xf = xfs[frame];
+            const unsigned hi_limit = lens_hi_limit(xf, lk);
             const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
             const RowC rc = row_consts(xf, y);
             int iu[PXT], iv[PXT], o[PXT][3];
-            coord_q5x4(rc, xf, lk, s_tab, x0, iu, iv);
+            coord_q5x4(rc, xf, lk, hi_limit, s_tab, x0, iu, iv);
             remap4<DEPTH, BORDER>(s, iu, iv, A.cval, o);
 #pragma unroll
             for (int i = 0; i < PXT; i++)
@@ -1054,6 +1079,7 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const d
 {
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     load_lens_table(lens, s_tab);
+    const unsigned hi_limit = lens_hi_limit(xf, lk);
     const int j = blockIdx.x*64 + (threadIdx.x & 63);
     if (j >= w) return;
 #pragma unroll 1
@@ -1063,7 +1089,7 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const d
         const RowC rc = row_consts(xf, i);
         if (FIXED) {
             int iu, iv;
-            coord_q5(rc, xf, lk, s_tab, j, iu, iv);
+            coord_q5(rc, xf, lk, hi_limit, s_tab, j, iu, iv);
             int16_t* m1 = (int16_t*)(map1 + (size_t)i*m1step);
             uint16_t* m2 = (uint16_t*)(map2 + (size_t)i*m2step);
             // one 4-byte store for the (x,y) pair; (short) cast wraps (Q1)
@@ -1074,8 +1100,8 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const d
             double2 o;
             unsigned qhi;
             coord_fast(rc, s_tab, j, X, Y, W, qhi, o.x, o.y);
-            if (!lens_ok(W, qhi))
-                o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
+            if (!lens_ok(W, qhi, hi_limit)) { ray_cold(rc, j, X, Y, W);
+                o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W); }
             ((float*)(map1 + (size_t)i*m1step))[j] = (float)(o.x*(1.0/32));
             ((float*)(map2 + (size_t)i*m2step))[j] = (float)(o.y*(1.0/32));
         }
@@ -1322,6 +1348,10 @@ int get_lens(Ctx* c, const double* D, hipStream_t stream, const double** dev, Le
     for (int i = 0; i < 4; i++) {
         if (!(D[i] == D[i]) || fabs(D[i]) > 1e6) return fail(GF_ERR_INVALID_ARG, "lens: distortion coefficient %s%lld is not finite", "", i);
         lk->k[i] = D[i];
+    }
+    {   // |theta_d| <= theta_max (1 + |k1| theta_max^2 + ...) for theta <= atan(sqrt(255))
+        const double tm = atan(sqrt((double)((1 << LENS_OCT) - 1))), t2 = tm*tm;
+        lk->bound = tm*(1 + t2*(fabs(D[0]) + t2*(fabs(D[1]) + t2*(fabs(D[2]) + t2*fabs(D[3])))));
     }
     std::lock_guard<std::mutex> g(c->mu);
     c->tick++;

@@ -373,3 +373,39 @@ def test_two_threads_two_streams_two_lenses(gpu, orc):
     for t in th:
         t.join()
     assert [j["bad"] for j in jobs] == [0, 0]
+
+
+def test_degenerate_transforms_match_oracle(gpu, orc):
+    """Transforms nobody should pass -- NaN / inf entries, a zero matrix, a camera looking backwards, a 1e6x zoom -- must
+    neither fault nor diverge from the reference semantics: NaN/overflowing coordinates round to INT_MIN (cvRound), wrap
+    to (0,0) in the int16 map and are handled by the border rules."""
+    from gyroflow_amd import cv
+    rng = np.random.default_rng(99)
+    sh, sw, dh, dw = 60, 80, 48, 64
+    src = _rand_img(rng, sh, sw, np.uint8)
+    K = np.array([[50., 0, 40], [0, 50., 30], [0, 0, 1]]); D = np.array([0.03, -0.01, 0.004, 0.001])
+    base = np.concatenate([np.linalg.inv(K).ravel(), [50., 50.], [40., 30.]])
+    cases = []
+    for kind in range(8):
+        x = base.copy()
+        if kind == 0: x[0] = np.nan
+        elif kind == 1: x[6] = np.inf
+        elif kind == 2: x[:9] = 0.0
+        elif kind == 3: x[6:9] = [0, 0, -1.0]                 # _w < 0 everywhere
+        elif kind == 4: x[:6] *= 1e6                          # t far beyond the lens table
+        elif kind == 5: x[9:11] = [np.inf, -np.inf]
+        elif kind == 6: x[:9] = rng.normal(0, 1e3, 9)
+        elif kind == 7: x[11:13] = [1e300, np.nan]
+        cases.append(x)
+    xf = np.stack(cases)
+    frames = torch.from_numpy(np.stack([src] * len(cases))).to(gpu)
+    for border in (0, 1, 5):
+        prev = _rand_img(rng, dh, dw, np.uint8)
+        dst = torch.from_numpy(np.stack([prev] * len(cases))).to(gpu)
+        got = cv.undistort_rotate(frames, D, cv.xforms_to_device(xf, gpu), (dw, dh), dst=dst, borderMode=border, borderValue=(1, 2, 3)).cpu().numpy()
+        for k, x in enumerate(cases):
+            Kk = np.array([[x[9], 0, x[11]], [0, x[10], x[12]], [0, 0, 1]])
+            with np.errstate(all="ignore"):
+                m1, m2 = orc.fisheye_init_undistort_rectify_map(Kk, D, np.eye(3), np.eye(3), (dw, dh), orc.CV_16SC2, iR=x[:9].reshape(3, 3))
+            want = orc.remap_linear(src, m1, m2, dst=prev.copy(), borderMode=border, borderValue=(1, 2, 3))
+            assert np.array_equal(got[k], want), "degenerate case %d, border %d" % (k, border)
