@@ -1139,24 +1139,13 @@ __device__ __forceinline__ int border_interp(int p, int len, int border1)
     return -1;
 }
 
-// SEP = true: separable maps (NonlinearStretch): mx is one row of dw floats, my one column of dh floats; blockIdx.z = frame.
-template <bool SEP>
-__global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __restrict__ src, int sw, int sh, size_t sstep, size_t sframe,
-                                                             uint8_t* dst, int dw, int dh, size_t dstep, size_t dframe,
-                                                             const uint8_t* __restrict__ mx, size_t mxstep,
-                                                             const uint8_t* __restrict__ my, size_t mystep,
-                                                             const int16_t* __restrict__ tab, int border, int c0, int c1, int c2)
+// One bicubic output pixel, cv::remapBicubic semantics (imgwarp.cpp), any border case.  (isx, isy) = cvRound(32 * map).
+__device__ __forceinline__ void cubic_px(const uint8_t* __restrict__ src, int sw, int sh, size_t sstep, uint8_t* D, int isx, int isy,
+                                         const int16_t* __restrict__ tab, int border, int c0, int c1, int c2)
 {
-    const int dx = blockIdx.x*64 + (threadIdx.x & 63), dy = blockIdx.y*4 + (threadIdx.x >> 6);
-    if (dx >= dw || dy >= dh) return;
-    src += (size_t)blockIdx.z*sframe; dst += (size_t)blockIdx.z*dframe;
-    const float fxm = SEP ? ((const float*)mx)[dx] : ((const float*)(mx + (size_t)dy*mxstep))[dx];
-    const float fym = SEP ? ((const float*)my)[dy] : ((const float*)(my + (size_t)dy*mystep))[dx];
-    const int isx = cv_round_f(__fmul_rn(fxm, 32.f)), isy = cv_round_f(__fmul_rn(fym, 32.f));
     const int a = (isy & 31)*32 + (isx & 31);
     const int sx = sat_s16(isx >> INTER_BITS) - 1, sy = sat_s16(isy >> INTER_BITS) - 1;
     const int16_t* w = tab + a*16;
-    uint8_t* D = dst + (size_t)dy*dstep + dx*3;
     const int cval[3] = {c0, c1, c2};
     const unsigned width1 = max(sw - 3, 0), height1 = max(sh - 3, 0);
     if ((unsigned)sx < width1 && (unsigned)sy < height1) {
@@ -1203,6 +1192,279 @@ __global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __res
         }
         int v = (sum + (1 << 14)) >> 15;
         D[k] = (uint8_t)(v < 0 ? 0 : v > 255 ? 255 : v);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_remap_cubic_u8c3(const uint8_t* __restrict__ src, int sw, int sh, size_t sstep,
+                                                             uint8_t* dst, int dw, int dh, size_t dstep,
+                                                             const uint8_t* __restrict__ mx, size_t mxstep,
+                                                             const uint8_t* __restrict__ my, size_t mystep,
+                                                             const int16_t* __restrict__ tab, int border, int c0, int c1, int c2)
+{
+    const int dx = blockIdx.x*64 + (threadIdx.x & 63), dy = blockIdx.y*4 + (threadIdx.x >> 6);
+    if (dx >= dw || dy >= dh) return;
+    const float fxm = ((const float*)(mx + (size_t)dy*mxstep))[dx], fym = ((const float*)(my + (size_t)dy*mystep))[dx];
+    cubic_px(src, sw, sh, sstep, dst + (size_t)dy*dstep + dx*3, cv_round_f(__fmul_rn(fxm, 32.f)), cv_round_f(__fmul_rn(fym, 32.f)),
+             tab, border, c0, c1, c2);
+}
+
+// K5s: NonlinearStretch's bicubic remap with separable maps (map x depends on the column, map y on the row), batched.
+// A thread owns one output column of a 256-column x SV_ROWS-row strip and walks down it.  Because the source row of an
+// output row is the same for every column, consecutive output rows share source rows *uniformly*: the thread keeps the
+// four source rows of its 4x4 window in registers -- each as six (tap, tap) halfword pairs ready for v_dot2_i32_i16 --
+// and, for groups of SV_G output rows that read consecutive source rows, fetches only the rows that are new (one 12-byte
+// load per output pixel when the vertical scale is 1, instead of four; the group's loads are in flight together) and no
+// weight-table traffic: the 32 KB Q15 table sits in LDS.  Four neighbouring lanes pack their 12 output bytes into three
+// dword stores.  Rows that do not step by one (other vertical scales) and pixels whose window touches the frame's edge
+// take cubic_px.
+constexpr int SV_ROWS = 48;
+constexpr int SV_G = 4;                   // output rows per group of the fast path
+typedef short short2_t __attribute__((ext_vector_type(2)));
+
+struct SvRow { uint32_t p[6]; };          // (B0,B1) (B2,B3) (G0,G1) (G2,G3) (R0,R1) (R2,R3) as halfword pairs
+struct __attribute__((packed, aligned(1))) SvRaw { uint32_t a, b, c; };     // 12 bytes: B0 G0 R0 B1 | G1 R1 B2 G2 | R2 B3 G3 R3
+
+__device__ __forceinline__ SvRow sv_unpack(const SvRaw d)
+{
+    SvRow r;
+    r.p[0] = __builtin_amdgcn_perm(d.a, d.a, 0x0c030c00u);      // B0, B1 = a.b0, a.b3
+    r.p[1] = __builtin_amdgcn_perm(d.c, d.b, 0x0c050c02u);      // B2, B3 = b.b2, c.b1
+    r.p[2] = __builtin_amdgcn_perm(d.b, d.a, 0x0c040c01u);      // G0, G1 = a.b1, b.b0
+    r.p[3] = __builtin_amdgcn_perm(d.c, d.b, 0x0c060c03u);      // G2, G3 = b.b3, c.b2
+    r.p[4] = __builtin_amdgcn_perm(d.b, d.a, 0x0c050c02u);      // R0, R1 = a.b2, b.b1
+    r.p[5] = __builtin_amdgcn_perm(d.c, d.c, 0x0c030c00u);      // R2, R3 = c.b0, c.b3
+    return r;
+}
+
+__device__ __forceinline__ int sv_dot(uint32_t a, uint32_t w, int acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a), __builtin_bit_cast(short2_t, w), acc, false);
+}
+
+// One pixel from the window rows U0..U3 (source rows sy..sy+3) and the table entry's 16 halfwords (w0, w1):
+// returns B | G << 8 | R << 16.
+__device__ __forceinline__ uint32_t sv_pixel(const SvRow& U0, const SvRow& U1, const SvRow& U2, const SvRow& U3, const uint4 w0, const uint4 w1)
+{
+    int sb = 1 << 14, sg = 1 << 14, sr = 1 << 14;
+#define SV_ROW(U, WA, WB)                                                                   \
+    sb = sv_dot(U.p[0], WA, sb); sb = sv_dot(U.p[1], WB, sb);                               \
+    sg = sv_dot(U.p[2], WA, sg); sg = sv_dot(U.p[3], WB, sg);                               \
+    sr = sv_dot(U.p[4], WA, sr); sr = sv_dot(U.p[5], WB, sr);
+    SV_ROW(U0, w0.x, w0.y) SV_ROW(U1, w0.z, w0.w) SV_ROW(U2, w1.x, w1.y) SV_ROW(U3, w1.z, w1.w)
+#undef SV_ROW
+    uint32_t B = (uint32_t)min(max(sb >> 15, 0), 255), G = (uint32_t)min(max(sg >> 15, 0), 255), R = (uint32_t)min(max(sr >> 15, 0), 255);
+    // The empty asm keeps the compiler from fusing two clamps and the byte packing into v_ashr_pk_u8_i32 (gfx950): the
+    // code it generated around that instruction relies on the destination's upper half being zero, and pixels came out
+    // wrong on MI355X (tests/test_gpu_parity.py::test_superview_separable_maps_batched).
+    asm("" : "+v"(G));
+    return B | (G << 8) | (R << 16);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __restrict__ src, int sw, int sh, unsigned sstep, size_t sframe,
+                                                            uint8_t* __restrict__ dst, int dw, int dh, size_t dstep, size_t dframe,
+                                                            const float* __restrict__ mx, const float* __restrict__ my,
+                                                            const int16_t* __restrict__ tab, int border, int c0, int c1, int c2,
+                                                            unsigned strips_x, unsigned strips_y, unsigned n_work, int dst_vec_ok, int src_vec_ok)
+{
+    static_assert(SV_ROWS <= 64, "one lane per strip row holds that row's map value");
+    __shared__ uint4 s_tab[2048];                                   // 1024 entries x 16 halfwords
+    for (int i = threadIdx.x; i < 2048; i += BLOCK) s_tab[i] = ((const uint4*)tab)[i];
+    __syncthreads();
+    const unsigned per_frame = strips_x*strips_y;
+    const int lane = threadIdx.x & 63;
+    const bool transparent = border == GF_BORDER_TRANSPARENT;
+    const int border1 = transparent ? 4 : border;                      // taps of a written pixel reflect (as cubic_px)
+    const uint32_t cpix = (uint32_t)(c0 & 255) | ((uint32_t)(c1 & 255) << 8) | ((uint32_t)(c2 & 255) << 16);
+    SvRaw cpat;                                                         // four pixels of the constant colour
+    cpat.a = cpix | (cpix << 24); cpat.b = (cpix >> 8) | (cpix << 16); cpat.c = (cpix >> 16) | (cpix << 8);
+#pragma unroll 1
+    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const unsigned frame = v / per_frame, t = v - frame*per_frame;
+        const unsigned syi = t / strips_x, sxi = t - syi*strips_x;
+        const uint8_t* S = src + (size_t)frame*sframe;
+        uint8_t* Dst = dst + (size_t)frame*dframe;
+        const int x = (int)(sxi*BLOCK + threadIdx.x);
+        const bool col_ok = x < dw;
+        const int isx = cv_round_f(__fmul_rn(mx[col_ok ? x : dw - 1], 32.f));
+        const int sx = sat_s16(isx >> INTER_BITS) - 1, fx = isx & 31;
+        // A lane whose four tap columns lie inside the row fetches them as one 12-byte load; an edge lane resolves each
+        // tap column through the border rule once per strip (xs3 = byte offset in the row, -1 = the constant colour).
+        const bool direct = sx >= 0 && sx + 3 <= sw - 1;
+        const unsigned off_direct = direct ? (unsigned)sx*3u : 0u;
+        // When every lane of the wave is direct and the wave's windows span at most 64 aligned dwords of the row, the wave
+        // fetches those dwords once (one aligned dword per lane) and each lane collects its 12 bytes from its neighbours'
+        // registers (ds_bpermute): a quarter of the bytes through the vector-memory return path.
+        int sx_lo = direct ? sx : INT_MAX, sx_hi = direct ? sx : INT_MIN;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) { sx_lo = min(sx_lo, __shfl_xor(sx_lo, o)); sx_hi = max(sx_hi, __shfl_xor(sx_hi, o)); }
+        const unsigned coop_base = (unsigned)__builtin_amdgcn_readfirstlane(max(sx_lo, 0)*3) & ~3u;
+        const unsigned coop_end = (unsigned)__builtin_amdgcn_readfirstlane(max(sx_hi, 0)*3) + 12u;     // one past the last byte needed
+        const bool coop = src_vec_ok && __all(direct) && coop_end - coop_base <= 256u && coop_end <= (((unsigned)sw*3u) & ~3u);
+        const unsigned coop_ld = coop_base + 4u*(unsigned)lane;        // this lane's dword of the row
+        const unsigned coop_bo = off_direct - coop_base;                // this lane's window within the fetched dwords
+        const int coop_sel = (int)(coop_bo & ~3u);                      // byte address of its first dword for ds_bpermute
+        const unsigned coop_sh = (coop_bo & 3u)*8u;
+        int xs3[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { const int t = border_interp(sx + q, sw, border1); xs3[q] = t < 0 ? -1 : t*3; }
+        const bool lane_wr = col_ok && !(transparent && (unsigned)(sx + 1) >= (unsigned)sw);
+        // lanes 4q..4q+3 write 12 contiguous bytes: when all four write, three of them store one dword each
+        const unsigned long long wr_mask = __ballot(lane_wr);
+        const bool quad_full = dst_vec_ok && ((wr_mask >> (lane & ~3)) & 0xFull) == 0xFull;
+        const int y0 = (int)(syi*SV_ROWS), nrows = min(SV_ROWS, dh - y0);
+        const int isy_lane = cv_round_f(__fmul_rn(my[min(y0 + lane, dh - 1)], 32.f));      // lane i: the strip's row i
+
+        auto load_row = [&](int sy) -> SvRaw {                          // sy is wave-uniform
+            const int ry = border_interp(sy, sh, border1);
+            SvRaw r = cpat;
+            if (ry >= 0) {
+                const uint8_t* rowp = S + (size_t)ry*sstep;
+                if (direct) r = *(const SvRaw*)(rowp + off_direct);
+                else if (col_ok) {
+                    uint32_t t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        t[q] = cpix;
+                        if (xs3[q] >= 0) { const uint8_t* e = rowp + xs3[q]; t[q] = (uint32_t)e[0] | ((uint32_t)e[1] << 8) | ((uint32_t)e[2] << 16); }
+                    }
+                    r.a = t[0] | (t[1] << 24); r.b = (t[1] >> 8) | (t[2] << 16); r.c = (t[2] >> 16) | (t[3] << 8);
+                }
+            }
+            return r;
+        };
+        auto store_px = [&](int y, uint32_t px, int sy) {
+            // right neighbour's pixel within the quad (quad_perm [1,2,3,3]); executed by every lane of the wave
+            const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);
+            if (transparent && (unsigned)(sy + 1) >= (unsigned)sh) return;          // uniform: the whole row stays untouched
+            uint8_t* D = Dst + (size_t)y*dstep + (size_t)x*3;
+            if (quad_full) {                                                // the quad's 12 bytes start 4-byte aligned
+                const int j = lane & 3;
+                if (j < 3) *(uint32_t*)(D + j) = __builtin_amdgcn_alignbit(nb, px << 8, 8u + 8u*(unsigned)j);
+            } else if (lane_wr) {
+                D[0] = (uint8_t)px; D[1] = (uint8_t)(px >> 8); D[2] = (uint8_t)(px >> 16);
+            }
+        };
+
+        SvRow R[SV_G + 3];                                              // source rows base .. base + SV_G + 2 of the current group
+#pragma unroll
+        for (int k = 0; k < SV_G + 3; k++)
+#pragma unroll
+            for (int j = 0; j < 6; j++) R[k].p[j] = 0;
+        auto row_of = [&](int r) { return sat_s16(__builtin_amdgcn_readlane(isy_lane, r) >> INTER_BITS) - 1; };      // r < 64, uniform
+        auto group_runs = [&](int r, int sy) {                          // output rows r .. r + SV_G - 1 read source rows sy, sy + 1, ...
+            bool ok = true;
+#pragma unroll
+            for (int k = 1; k < SV_G; k++) ok = ok && row_of(r + k) == sy + k;
+            return ok;
+        };
+        int i = 0;
+
+        // Fast loop: a wave whose lanes all fetch cooperatively and all write.  Straight-line code, no branch around a
+        // memory instruction, so that the rows the next group adds are requested *before* this group's stores are queued
+        // and waiting for them does not wait for the stores (vector loads and stores complete in issue order).
+        if (coop && !transparent && dst_vec_ok && wr_mask == ~0ull) {
+            const unsigned ld_off = min(coop_ld, (coop_end - 1u) & ~3u);            // lanes past the span re-read its last dword
+            const int qj = lane & 3;
+            // lanes 0..2 of a quad write dword qj of its 12 bytes; lane 3 repeats lane 2's store (same address, same value)
+            uint8_t* const Dlane = Dst + (size_t)x*3 + (qj < 3 ? qj : -1);
+            const unsigned st_sh = qj < 3 ? 8u + 8u*(unsigned)qj : 24u;
+            auto rows_ok = [&](int sy) { return border1 != GF_BORDER_CONSTANT || (sy >= 0 && sy + SV_G + 2 <= sh - 1); };
+            auto loadw = [&](int sy) { return *(const uint32_t*)(S + (size_t)max(border_interp(sy, sh, border1), 0)*sstep + ld_off); };
+            auto gather = [&](uint32_t w) {
+                const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(coop_sel, (int)w);
+                const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(coop_sel + 4, (int)w);
+                const uint32_t w2 = (uint32_t)__builtin_amdgcn_ds_bpermute(coop_sel + 8, (int)w);
+                const uint32_t w3 = (uint32_t)__builtin_amdgcn_ds_bpermute(coop_sel + 12, (int)w);
+                SvRaw r;
+                r.a = __builtin_amdgcn_alignbit(w1, w0, coop_sh); r.b = __builtin_amdgcn_alignbit(w2, w1, coop_sh); r.c = __builtin_amdgcn_alignbit(w3, w2, coop_sh);
+                return sv_unpack(r);
+            };
+#pragma unroll 1
+            while (i + SV_G <= nrows) {
+                int sy0 = row_of(i);
+                if (!(group_runs(i, sy0) && rows_ok(sy0))) break;
+                uint32_t w[3], nw[SV_G];
+#pragma unroll
+                for (int k = 0; k < 3; k++) w[k] = loadw(sy0 + k);
+#pragma unroll
+                for (int k = 0; k < SV_G; k++) nw[k] = loadw(sy0 + 3 + k);
+#pragma unroll
+                for (int k = 0; k < 3; k++) R[k] = gather(w[k]);
+#pragma unroll 1
+                for (;;) {
+#pragma unroll
+                    for (int k = 0; k < SV_G; k++) R[3 + k] = gather(nw[k]);
+                    const int i2 = i + SV_G;
+                    const int sy1 = row_of(min(i2, 63 - SV_G));
+                    const bool more = i2 + SV_G <= nrows && sy1 == sy0 + SV_G && group_runs(min(i2, 63 - SV_G), sy1) && rows_ok(sy1);
+#pragma unroll
+                    for (int k = 0; k < SV_G; k++) nw[k] = loadw(sy0 + SV_G + 3 + k);      // used only when `more`
+#pragma unroll
+                    for (int k = 0; k < SV_G; k++) {
+                        const int e = ((__builtin_amdgcn_readlane(isy_lane, i + k) & 31)*32 + fx)*2;
+                        const uint32_t px = sv_pixel(R[k], R[k + 1], R[k + 2], R[k + 3], s_tab[e], s_tab[e + 1]);
+                        const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
+                        const uint32_t lf = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0x90, 0xF, 0xF, true);      // quad_perm [0,0,1,2]: left neighbour
+                        *(uint32_t*)(Dlane + (size_t)(y0 + i + k)*dstep) = __builtin_amdgcn_alignbit(qj < 3 ? nb : px, (qj < 3 ? px : lf) << 8, st_sh);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 3; k++) R[k] = R[SV_G + k];
+                    i = i2; sy0 = sy1;
+                    if (!more) break;
+                }
+            }
+        }
+
+        // Generic rows: edge waves, the transparent border, vertical steps other than 1, and what the fast loop left.
+        int carried = INT_MIN;                                          // R[0..2] hold source rows carried .. carried + 2
+#pragma unroll 1
+        while (i < nrows) {
+            const int sy0 = row_of(i);
+            const bool run = i + SV_G <= nrows && group_runs(min(i, 63 - SV_G), sy0);
+            const bool fresh = carried != sy0;                          // uniform: the three carried rows are not the ones needed
+            if (run) {
+                SvRaw raw[SV_G + 3];
+                if (fresh) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) raw[k] = load_row(sy0 + k);
+                }
+#pragma unroll
+                for (int k = 3; k < SV_G + 3; k++) raw[k] = load_row(sy0 + k);
+                if (fresh) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) R[k] = sv_unpack(raw[k]);
+                }
+#pragma unroll
+                for (int k = 3; k < SV_G + 3; k++) R[k] = sv_unpack(raw[k]);
+#pragma unroll
+                for (int k = 0; k < SV_G; k++) {
+                    const int e = ((__builtin_amdgcn_readlane(isy_lane, i + k) & 31)*32 + fx)*2;
+                    store_px(y0 + i + k, sv_pixel(R[k], R[k + 1], R[k + 2], R[k + 3], s_tab[e], s_tab[e + 1]), sy0 + k);
+                }
+#pragma unroll
+                for (int k = 0; k < 3; k++) R[k] = R[SV_G + k];
+                carried = sy0 + SV_G;
+                i += SV_G;
+            } else {                                                    // one row
+                SvRaw raw[4];
+                if (fresh) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) raw[k] = load_row(sy0 + k);
+                }
+                raw[3] = load_row(sy0 + 3);
+                if (fresh) {
+#pragma unroll
+                    for (int k = 0; k < 3; k++) R[k] = sv_unpack(raw[k]);
+                }
+                R[3] = sv_unpack(raw[3]);
+                const int e = ((__builtin_amdgcn_readlane(isy_lane, i) & 31)*32 + fx)*2;
+                store_px(y0 + i, sv_pixel(R[0], R[1], R[2], R[3], s_tab[e], s_tab[e + 1]), sy0);
+#pragma unroll
+                for (int k = 0; k < 3; k++) R[k] = R[k + 1];
+                carried = sy0 + 1;
+                i += 1;
+            }
+        }
     }
 }
 
@@ -1565,7 +1827,7 @@ GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, in
     int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
     DeviceGuard dg(((Ctx*)ctx)->device);
     dim3 grid((dw + 63)/64, (dh + 3)/4);
-    hipLaunchKernelGGL(k_remap_cubic_u8c3<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, (size_t)0, dst, dw, dh, dstep, (size_t)0,
+    hipLaunchKernelGGL(k_remap_cubic_u8c3, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, dst, dw, dh, dstep,
                        (const uint8_t*)mx, mxs, (const uint8_t*)my, mys, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
     HIP_TRY(hipGetLastError());
     return GF_OK;
@@ -1581,9 +1843,16 @@ GF_API int gf_superview_cubic_u8c3(void* ctx, const uint8_t* src, int sw, int sh
     if (!mapy_col || ((uintptr_t)mapx_row & 3) || ((uintptr_t)mapy_col & 3)) return fail(GF_ERR_INVALID_ARG, "%s: null or misaligned map", "gf_superview_cubic_u8c3");
     int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
     DeviceGuard dg(((Ctx*)ctx)->device);
-    dim3 grid((dw + 63)/64, (dh + 3)/4, n_frames);
-    hipLaunchKernelGGL(k_remap_cubic_u8c3<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe,
-                       (const uint8_t*)mapx_row, (size_t)0, (const uint8_t*)mapy_col, (size_t)0, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
+    Ctx* c = (Ctx*)ctx;
+    const unsigned strips_x = (unsigned)(dw + BLOCK - 1)/BLOCK, strips_y = (unsigned)(dh + SV_ROWS - 1)/SV_ROWS;
+    const unsigned long long n_work = (unsigned long long)strips_x*strips_y*(unsigned)n_frames;
+    if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many strips in one call (%lld)", "gf_superview_cubic_u8c3", (long long)n_work);
+    static const unsigned sv_wg_per_cu = []{ const char* e = getenv("GF_SV_WG_PER_CU"); int v = e ? atoi(e) : 0; return (unsigned)(v > 0 && v <= 16 ? v : 4); }();
+    unsigned blocks = (unsigned)c->n_cu*sv_wg_per_cu;              // persistent: 32 KB of LDS and ~100 VGPRs per workgroup, four resident per CU
+    if (blocks > n_work) blocks = (unsigned)n_work;
+    hipLaunchKernelGGL(k_superview_cubic, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, (unsigned)sstep, sframe, dst, dw, dh, dstep, dframe,
+                       mapx_row, mapy_col, c->cubic_tab, border, cval[0], cval[1], cval[2], strips_x, strips_y, (unsigned)n_work,
+                       (((uintptr_t)dst | dstep | dframe) & 3) == 0 ? 1 : 0, (((uintptr_t)src | sstep | sframe) & 3) == 0 ? 1 : 0);
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
