@@ -38,6 +38,7 @@ SIGNATURES = {
     "gf_last_error": [],
     "gf_ctx_create": [_i, C.POINTER(_vp)],
     "gf_ctx_destroy": [_vp],
+    "gf_ctx_set_kernel_mode": [_vp, _i],
     "gf_make_frame_xform": [_dp, _dp, _dp, C.POINTER(FrameXform)],
     "gf_fisheye_maps_16sc2": [_vp, _dp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
     "gf_fisheye_maps_32f": [_vp, _dp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
@@ -97,6 +98,14 @@ def ctx(device_index):
             check(lib.gf_ctx_create(int(device_index), C.byref(h)))
             c = _ctxs[device_index] = h
     return c
+
+
+KERNEL_DIRECT, KERNEL_RP, KERNEL_RL = 0, 1, 2
+
+
+def set_kernel_mode(device_index, mode):
+    """A/B switch of the fused kernel / CV_16SC2 map kernel of a device's context (gf_ctx_set_kernel_mode)."""
+    check(load().gf_ctx_set_kernel_mode(ctx(device_index), int(mode)))
 
 
 def border_value(v):

@@ -64,10 +64,40 @@ constexpr unsigned LENS_HI_LIMIT = 0x3FF00000u + ((unsigned)LENS_OCT << 20);   /
 constexpr int LENS_SLOTS = 4;
 constexpr double ROUND_MAGIC = 6755399441055744.0;      // 1.5 * 2^52: low dword of (x + magic) = rint(x), |x| < 2^31
 
+// RP (row polynomials, see k_undistort_rotate_rp): output tiles of RT x RT pixels; per tile row the radial factor
+// G = S(t)/_w is evaluated at RP_N Chebyshev nodes and interpolated by a polynomial of degree RP_N - 1 in
+// z = (j - centre)/RP_HALF.
+constexpr int RT = 64;                                  // tile side
+constexpr int RT_TPR = RT/PXT;                          // 16 threads per tile row
+constexpr int RT_RPP = BLOCK/RT_TPR;                    // 16 rows per pass
+constexpr int RT_NPASS = RT/RT_RPP;                     // 4 passes
+constexpr int RP_N = 8;
+constexpr int RP_TAB_DOUBLES = RP_N*RP_N + RP_N;        // node values -> monomial coefficients (row-major), then the nodes
+constexpr double RP_HALF = RT/2.0;                      // the nodes span [-0.5, RT - 0.5]
+constexpr double RP_GUARD = 8.0;                        // singularities of G at least this many half tiles away
+// RL (LDS-staged source box of the RP kernel, u8): raw source rows at a fixed pitch, four rows per LDS-DMA instruction
+constexpr int RL_PITCH = 256;                           // bytes per box row in LDS (16 lanes x 16 bytes)
+#ifndef GF_RL_TAB_GLOBAL
+#define GF_RL_TAB_GLOBAL 1
+#endif
+#ifndef GF_RL_ROWS
+#define GF_RL_ROWS (GF_RL_TAB_GLOBAL ? 84 : 104)
+#endif
+constexpr int RL_ROWS = GF_RL_ROWS;                     // rows per box buffer (21 KB; two buffers)
+static_assert(RL_ROWS % 4 == 0, "four rows per LDS-DMA instruction");
+
 thread_local char g_err[512] = "";
 // A/B switch (tools/kbench): the LDS-staged variant of the fused kernel is correct but, as measured on MI355X, ~20 %
 // slower than the direct-gather kernel (more VALU work per pixel, three barriers per tile), so it is opt-in.
 const bool g_use_lds_tiles = getenv("GF_USE_LDS_TILES") != nullptr;
+// Kernel variants of the fused kernel and the CV_16SC2 map kernel (gf_ctx_set_kernel_mode; the environment variable GF_K1
+// = direct | rp | rl sets the default of new contexts): direct = per-pixel lens-table coordinates (kernel v4, the fastest
+// as measured on MI355X and the default), rp = RP coordinates (per-row polynomials) with taps gathered from the frame,
+// rl = RP coordinates and, for u8 frames, source taps staged through LDS by LDS-DMA.  The kernels of a mode use the same
+// coordinate arithmetic, so fused output == maps + remap bit for bit in every mode.
+const int g_k1_mode = !getenv("GF_K1") ? GF_KERNEL_DIRECT : !strcmp(getenv("GF_K1"), "rp") ? GF_KERNEL_RP : !strcmp(getenv("GF_K1"), "rl") ? GF_KERNEL_RL : GF_KERNEL_DIRECT;
+const unsigned WG_PER_CU_RP = getenv("GF_WG_PER_CU_RP") ? (unsigned)atoi(getenv("GF_WG_PER_CU_RP")) : 16u;
+const unsigned WG_PER_CU_RL = getenv("GF_WG_PER_CU_RL") ? (unsigned)atoi(getenv("GF_WG_PER_CU_RL")) : 8u;
 
 int fail(int code, const char* fmt, const char* a = "", long long b = 0)
 {
@@ -92,7 +122,9 @@ struct LensSlot {
 struct Ctx {
     int device;
     int n_cu;             // compute units of the device (sizes the persistent grid of the fused kernel)
+    int k1_mode;          // GF_KERNEL_*
     int16_t* cubic_tab;   // device, 1024*16 int16 (cv2 INTER_CUBIC Q15 table)
+    double* rp_tab;       // device, RP_TAB_DOUBLES doubles (build_rp_table)
     LensSlot lens[LENS_SLOTS];
     unsigned long long tick;
     std::mutex mu;
@@ -199,6 +231,34 @@ void build_lens_table(const double* D, double* tab)
             o[0] = qm;
             for (int j = 0; j < NC; j++) o[1 + j] = (double)ldexpl(a[j], -j*(e - LENS_SUB_BITS - 1));   // z = (q - q_mid)/hh
         }
+}
+
+// Host: RP table.  Nodes z_n = cos((2n+1) pi / 16); M = V^-1 with V[n][a] = z_n^a, so that the interpolating
+// polynomial's monomial coefficients are c = M * (values at the nodes).  Long double, rounded once.
+void build_rp_table(double* out)
+{
+    long double z[RP_N], A[RP_N][2*RP_N];
+    for (int n = 0; n < RP_N; n++) z[n] = cosl(M_PIl*(2*n + 1)/(2.0L*RP_N));
+    for (int n = 0; n < RP_N; n++) {
+        long double p = 1;
+        for (int a = 0; a < RP_N; a++) { A[n][a] = p; p *= z[n]; }
+        for (int a = 0; a < RP_N; a++) A[n][RP_N + a] = a == n ? 1.0L : 0.0L;
+    }
+    for (int c = 0; c < RP_N; c++) {                     // Gauss-Jordan with partial pivoting
+        int piv = c;
+        for (int r = c + 1; r < RP_N; r++) if (fabsl(A[r][c]) > fabsl(A[piv][c])) piv = r;
+        if (piv != c) for (int j = 0; j < 2*RP_N; j++) { long double t = A[c][j]; A[c][j] = A[piv][j]; A[piv][j] = t; }
+        const long double d = 1.0L/A[c][c];
+        for (int j = 0; j < 2*RP_N; j++) A[c][j] *= d;
+        for (int r = 0; r < RP_N; r++)
+            if (r != c) {
+                const long double f = A[r][c];
+                for (int j = 0; j < 2*RP_N; j++) A[r][j] -= f*A[c][j];
+            }
+    }
+    for (int a = 0; a < RP_N; a++)
+        for (int n = 0; n < RP_N; n++) out[a*RP_N + n] = (double)A[a][RP_N + n];
+    for (int n = 0; n < RP_N; n++) out[RP_N*RP_N + n] = (double)z[n];
 }
 
 // the kernel's table lookup, restated for the host (gf_lens_scale_host; CPU tests check it against long double)
@@ -730,6 +790,9 @@ template <int DEPTH, bool HI16 = false>
 __device__ __forceinline__ void store_px(uint8_t* drow, int x0, int dw, const int (*px)[3], unsigned keep, bool vec_ok)
 {
     typedef typename PixT<DEPTH>::T T;
+#ifdef GF_ABL_NOSTORE    /* tools/ ablation builds only: results are computed but (practically) never stored */
+    if (px[0][0] != 0x7fffffff) return;
+#endif
     if (vec_ok && keep == 0 && x0 + PXT <= dw) {
         if (DEPTH == GF_DEPTH_U8) {
             uint32_t w0, w1, w2;
@@ -867,6 +930,347 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
             store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
         }
 #endif
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RP: coordinates from per-row polynomials.
+// 32u = fx32 * _x * G + cx32 and 32v = fy32 * _y * G + cy32 with G = S(t) / _w.  _x, _y are linear in the column j, and
+// along an output row G is analytic in j with its nearest singularities (q = 1 + t = 0 and _w = 0) |P| / |column step
+// of iR| pixels away from a pixel with ray P = (_x, _y, _w) -- about one focal length of the output camera.  On a
+// 64-pixel row segment whose half width is at most 1/8 of that distance the polynomial through 8 Chebyshev nodes is
+// accurate to 2e-10 relative at worst (Bernstein ellipse parameter >= 16) and to rounding error for the BASELINE
+// configurations (parameter 110 for a 4K frame, 55 for 1080p: 55^-8 = 1e-14), the same class of error as the lens table
+// itself.  Per 64 x 64 tile every thread evaluates G twice through the lens table -- thread t at node t % 8 of tile rows
+// t / 8 and 32 + t / 8 -- and converts node values to one monomial coefficient of those rows (an 8-term dot product with a
+// row of the inverse Vandermonde matrix, build_rp_table; the eight nodes of a row sit in eight adjacent lanes of one
+// wave, so the exchange needs no barrier).  The tile's pixels then cost a degree-7 Horner evaluation (7 fma) instead of
+// the reciprocal, the table lookup and the degree-6 piece: 15 f64 operations per pixel instead of 31.
+// A row with a node that fails a check (ray behind the camera or outside the table, singularity too close, absurd focal
+// data) takes the per-pixel path (coord_q5x4).  k_undistort_rotate_rp and k_fisheye_maps_rp use the same functions on the
+// same tile grid, so their coordinates are identical bit for bit.
+static_assert(BLOCK/RP_N*2 == RT && RP_N == 8 && BLOCK == 256, "two node evaluations per thread and tile");
+#ifndef GF_RP_WAVES
+#define GF_RP_WAVES 2
+#endif
+#ifndef GF_RL_UNROLL
+#define GF_RL_UNROLL 1
+#endif
+
+struct RpShared {
+    double U[BLOCK/64][8][RP_N];    // wave-private: G at the nodes of the eight rows a wave evaluates at a time
+    double C[2][RT][RP_N];          // [buffer][tile row][power]: monomial coefficients in z
+    double M[RP_N][RP_N];           // inverse Vandermonde matrix (rp_tab)
+    int ok[2][RT];                  // the row may use its polynomial
+    int box[4][4];                  // [slot][min u, max u, min v, max v]: integer source positions of the tile's nodes
+};
+struct RpLane {
+    double z[PXT];                  // z of the thread's four pixel columns (the same in every tile)
+    double node_off;                // pixel offset of node a within the tile
+    int a, rsub;                    // this thread's node and row (rows rsub and 32 + rsub) in rp_prepare
+};
+
+// Also copies the matrix into LDS and resets the box slots; the caller's next barrier orders both before their first use.
+__device__ __forceinline__ RpLane rp_lane_consts(const double* __restrict__ rp_tab, int tid, RpShared& S)
+{
+    RpLane L;
+    L.a = tid & (RP_N - 1); L.rsub = tid / RP_N;
+    if (tid < RP_N*RP_N) (&S.M[0][0])[tid] = rp_tab[tid];
+    if (tid < 16) (&S.box[0][0])[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+    L.node_off = (RP_HALF - 0.5) + RP_HALF*rp_tab[RP_N*RP_N + L.a];
+    const int lx = tid & (RT_TPR - 1);
+#pragma unroll
+    for (int e = 0; e < PXT; e++) L.z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);      // exact
+    return L;
+}
+
+// All threads: coefficients and row flags of tile (tx, ty) -> S.C[buf], S.ok[buf]; with BOX also the extent of the
+// tile's rim nodes' source positions -> S.box[slot].
+template <bool BOX>
+__device__ __forceinline__ void rp_prepare(const Xf& xf, const LensK& lk, const double2* __restrict__ tab, const RpLane& L, int tx, int ty,
+                                           RpShared& S, int buf, int slot, int dh)
+{
+    const unsigned hi_limit = lens_hi_limit(xf, lk);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    const double dj = (double)(tx*RT) + L.node_off;
+    const double G2 = (RP_GUARD*RP_HALF)*(RP_GUARD*RP_HALF);
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        const int r = half*(RT/2) + L.rsub;
+        const RowC rc = row_consts(xf, ty*RT + r);
+        const double X = __fma_rn(dj, rc.ax, rc.rx), Y = __fma_rn(dj, rc.ay, rc.ry), W = __fma_rn(dj, rc.aw, rc.rw);
+        double iw = __builtin_amdgcn_rcp(W);
+        iw = __fma_rn(__fma_rn(-W, iw, 1.0), iw, iw);
+        const double x = X*iw, y = Y*iw;
+        const double q = __fma_rn(x, x, __fma_rn(y, y, 1.0));
+        const unsigned qhi = (unsigned)__double2hiint(q);
+        const unsigned off = (qhi >> (20 - LENS_SUB_BITS - 6)) & ((unsigned)(LENS_N - 1) << 6);
+        const double2* c = (const double2*)((const char*)tab + off);
+        const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+        const double dz = q - c0.x;
+        double Sc = __fma_rn(c3.y, dz, c3.x);
+        Sc = __fma_rn(Sc, dz, c2.y); Sc = __fma_rn(Sc, dz, c2.x); Sc = __fma_rn(Sc, dz, c1.y); Sc = __fma_rn(Sc, dz, c1.x);
+        Sc = __fma_rn(Sc, dz, c0.y);
+        const double G = Sc*iw;
+        // distance to the nearest singularity of G along the row, in pixels: |P| / |step| (q = 0) and _w / |step of _w| (_w = 0)
+        const double a2 = rc.ax*rc.ax + rc.ay*rc.ay + rc.aw*rc.aw, W2 = W*W;
+        const bool ok = lens_ok(W, qhi, hi_limit) && W2*q >= G2*a2 && W2 >= G2*(rc.aw*rc.aw);
+        const unsigned long long mask = __ballot(ok);                  // a row's RP_N nodes sit in adjacent lanes
+        const bool row_ok = ((mask >> (lane & ~(RP_N - 1))) & ((1u << RP_N) - 1)) == ((1u << RP_N) - 1);
+        if (L.a == 0) S.ok[buf][r] = row_ok ? 1 : 0;
+        // Box: the tile's corner nodes and the end nodes of its two middle rows (8 samples; LDS atomics from many lanes to
+        // one address are serialised and cost more than the tile itself).  The margin of rl_box covers the bulge between them.
+        if (BOX && row_ok && (L.a == 0 || L.a == RP_N - 1) && (L.rsub == 0 || L.rsub == RT/2 - 1)) {
+            const int su = __double2loint(__fma_rn(X*G, rc.fx32, rc.cx32) + ROUND_MAGIC) >> INTER_BITS;
+            const int sv = __double2loint(__fma_rn(Y*G, rc.fy32, rc.cy32) + ROUND_MAGIC) >> INTER_BITS;
+            atomicMin(&S.box[slot][0], su); atomicMax(&S.box[slot][1], su); atomicMin(&S.box[slot][2], sv); atomicMax(&S.box[slot][3], sv);
+        }
+        // node values -> coefficient L.a of row r, through the wave's scratch rows (LDS operations of one wave execute in
+        // program order; the empty asm statements keep the compiler from moving the reads above the writes and back)
+        S.U[wave][L.rsub & 7][L.a] = G;
+        asm volatile("" ::: "memory");
+        const double2* u = (const double2*)S.U[wave][L.rsub & 7];
+        const double2* m = (const double2*)S.M[L.a];
+        const double2 u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3], m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
+        asm volatile("" ::: "memory");
+        double cf = m0.x*u0.x;
+        cf = __fma_rn(m0.y, u0.y, cf); cf = __fma_rn(m1.x, u1.x, cf); cf = __fma_rn(m1.y, u1.y, cf);
+        cf = __fma_rn(m2.x, u2.x, cf); cf = __fma_rn(m2.y, u2.y, cf); cf = __fma_rn(m3.x, u3.x, cf); cf = __fma_rn(m3.y, u3.y, cf);
+        S.C[buf][r][L.a] = cf;
+    }
+}
+
+// Q5 integers of the thread's PXT pixels (columns x0 .. x0 + 3 of the row with constants rc) from the row's coefficients:
+// low dwords of 32u + mu and 32v + mv.  mu = mv = ROUND_MAGIC gives rint(32u), rint(32v); ROUND_MAGIC - 32 k (k an integer)
+// gives them relative to source position k with the same ties (the offset is even).
+__device__ __forceinline__ void rp_coords(const RowC& rc, const double* crow, const double* z, int x0, double mu, double mv, int* iu, int* iv)
+{
+    static_assert(RP_N == 8, "Horner chain is written for degree 7");
+    const double2* c = (const double2*)crow;
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+#pragma unroll
+    for (int e = 0; e < PXT; e++) {
+        double G = __fma_rn(c3.y, z[e], c3.x);
+        G = __fma_rn(G, z[e], c2.y); G = __fma_rn(G, z[e], c2.x); G = __fma_rn(G, z[e], c1.y); G = __fma_rn(G, z[e], c1.x);
+        G = __fma_rn(G, z[e], c0.y); G = __fma_rn(G, z[e], c0.x);
+        const double dj = (double)(x0 + e);
+        const double X = __fma_rn(dj, rc.ax, rc.rx), Y = __fma_rn(dj, rc.ay, rc.ry);
+        iu[e] = __double2loint(__fma_rn(X*G, rc.fx32, rc.cx32) + mu);
+        iv[e] = __double2loint(__fma_rn(Y*G, rc.fy32, rc.cy32) + mv);
+    }
+}
+
+// The tile's source box (wave-uniform): tap positions bx0 .. bx1, by0 .. by1 (with their right and lower neighbours) are held
+// in LDS, row by0 + i at byte i * RL_PITCH, column byte offset (3 sx - bxB).
+struct RlBox {
+    bool on;
+    int bx0, by0;          // first tap position held
+    unsigned NXq, NYq;     // Q5 extents: positions with (iu - 32 bx0) < NXq and (iv - 32 by0) < NYq are held
+    unsigned bxB;          // byte offset within a source row of the box's first byte (16-byte aligned)
+    unsigned xoffB;        // 3 bx0 - bxB
+    int nrows;             // source rows held
+};
+
+__device__ __forceinline__ RlBox rl_box(const int* slot, int sw, int sh)
+{
+    RlBox B;
+    const int mnu = __builtin_amdgcn_readfirstlane(slot[0]), mxu = __builtin_amdgcn_readfirstlane(slot[1]);
+    const int mnv = __builtin_amdgcn_readfirstlane(slot[2]), mxv = __builtin_amdgcn_readfirstlane(slot[3]);
+    // +-2 positions of margin (the nodes stop 0.6 px short of the tile's edge columns), clamped to the positions whose
+    // taps all lie inside the frame; the subtraction order avoids overflow for the reset values INT_MAX / INT_MIN
+    B.bx0 = max(mnu, 2) - 2; const int bx1 = min(mxu, sw - 4) + 2;
+    B.by0 = max(mnv, 2) - 2; const int by1 = min(mxv, sh - 4) + 2;
+    B.bxB = ((unsigned)B.bx0*3u) & ~15u;
+    B.xoffB = (unsigned)B.bx0*3u - B.bxB;
+    B.nrows = by1 - B.by0 + 2;
+    const long long nbytes = (long long)(bx1 + 2)*3 - (long long)B.bxB;
+    B.on = sw >= 4 && sh >= 4 && B.bx0 <= bx1 && B.by0 <= by1 && nbytes <= RL_PITCH && B.nrows <= RL_ROWS;
+    B.NXq = B.on ? (unsigned)(bx1 - B.bx0 + 1) << INTER_BITS : 0u;
+    B.NYq = B.on ? (unsigned)(by1 - B.by0 + 1) << INTER_BITS : 0u;
+    return B;
+}
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+
+// Every wave: copy its share of the box rows (four per instruction: lane l fetches 16 bytes at column chunk l % 16 of row
+// 4 i + l / 16) from the frame into the LDS buffer, asynchronously (global_load_lds_dwordx4: the destination is M0 +
+// 16 * lane).  A chunk that would start at or past `limit` -- the last 16-byte chunk of the frame -- is read from there
+// instead: its bytes are never used.
+// The instruction is issued from an asm statement on purpose: for the builtin the compiler assumes that every later read of
+// the box array may depend on the copy in flight and waits for it -- and for every store issued since -- before each group
+// of tap reads, which serialises the whole kernel.  Hidden from its bookkeeping, the copy is waited for once, by rl_wait()
+// before the barrier that precedes the first read of that buffer.  M0 is saved and restored inside the statement.
+__device__ __forceinline__ void rl_issue(const RlBox& B, const uint8_t* __restrict__ frame, unsigned sstep, unsigned limit, uint4* buf, int wave, int lane)
+{
+    if (!B.on) return;
+    const unsigned lr = (unsigned)lane >> 4, lc = (unsigned)lane & 15u;
+    const int ngroups = (B.nrows + 3) >> 2;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr)buf;
+#pragma unroll 1
+    for (int i = wave; i < ngroups; i += BLOCK/64) {
+        const unsigned row = (unsigned)B.by0 + min(4u*(unsigned)i + lr, (unsigned)B.nrows - 1u);
+        const unsigned off = min(row*sstep + B.bxB + lc*16u, limit);
+        const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)i*1024u));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(frame) : "memory");
+    }
+}
+__device__ __forceinline__ void rl_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Workgroup barrier that orders LDS traffic only (no wait for outstanding global stores, unlike __syncthreads()).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+
+// Interior pixel from the LDS box, u8: ru, rv = Q5 coordinates relative to (bx0, by0).  Three aligned dwords per source row
+// cover the 6 tap bytes at any byte phase; v_alignbyte_b32 shifts them into the 8-byte window bilin_u8_rows expects.
+template <bool HI16>
+__device__ __forceinline__ void interp_u8_raw(const uint32_t* box, unsigned ru, unsigned rv, unsigned xoffB, int* out)
+{
+    const unsigned o = ((rv >> INTER_BITS) << 8) + __umul24(ru >> INTER_BITS, 3u) + xoffB;
+    static_assert(RL_PITCH == 256, "row shift");
+    const uint32_t* p = box + (o >> 2);
+    const uint32_t d0 = p[0], d1 = p[1], d2 = p[2], e0 = p[RL_PITCH/4], e1 = p[RL_PITCH/4 + 1], e2 = p[RL_PITCH/4 + 2];
+    const uint64_t ta = (uint64_t)__builtin_amdgcn_alignbyte(d1, d0, o) | ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, o) << 32);
+    const uint64_t tb = (uint64_t)__builtin_amdgcn_alignbyte(e1, e0, o) | ((uint64_t)__builtin_amdgcn_alignbyte(e2, e1, o) << 32);
+    bilin_u8_rows<HI16>(ta, tb, ru, rv, out);
+}
+
+// K1 with RP coordinates and (LDSBOX, u8 only) LDS-staged source taps.  Persistent; work items are (frame, 64 x 64 tile);
+// thread (lx, ly) = (tid % 16, tid / 16) produces columns 4 lx .. 4 lx + 3 of tile rows ly, ly + 16, ly + 32, ly + 48.
+// Per work item k:   prepare(k+1) | barrier B | issue the box of k+1 | compute k | barrier A
+//   prepare(k+1): coefficients -> C[(k+1)&1], extent of the source positions -> box slot (k+1)&3      (rp_prepare)
+//   barrier B:    every wave first waits for its own LDS-DMA of tile k (issued one work item earlier)
+//   issue:        every wave starts the LDS-DMA of its share of tile k+1's source box into buffer (k+1)&1    (rl_issue)
+//   compute k:    coordinates from C[k&1]; taps from box buffer k&1 when all four pixels of a thread lie inside the box,
+//                 otherwise straight from the frame (the box is an estimate, results never depend on it)
+//   barrier A:    nobody still reads C[k&1] / buffer k&1 when the next prepare / the issue after it overwrite them
+template <int DEPTH, int BORDER, bool LDSBOX>
+__global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                                const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work)
+{
+    static_assert(!LDSBOX || DEPTH == GF_DEPTH_U8, "the LDS box holds u8 pixels");
+    // LDSBOX: the lens table stays in global memory (two lookups per thread and tile, L1/L2 hits) so that three workgroups
+    // fit a CU's LDS; otherwise it is copied to LDS as in the other kernels
+    __shared__ double2 s_tab_lds[(LDSBOX && GF_RL_TAB_GLOBAL) ? 1 : LENS_DOUBLES/2];
+    __shared__ RpShared S;
+    __shared__ uint4 s_box[LDSBOX ? 2 : 1][LDSBOX ? RL_ROWS*RL_PITCH/16 : 1];
+    const double2* s_tab = (LDSBOX && GF_RL_TAB_GLOBAL) ? (const double2*)lens : s_tab_lds;
+    if (!(LDSBOX && GF_RL_TAB_GLOBAL)) load_lens_table(lens, s_tab_lds);
+    constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
+    const RpLane L = rp_lane_consts(rp_tab, (int)threadIdx.x, S);
+    const int lx = threadIdx.x & (RT_TPR - 1), ly = threadIdx.x / RT_TPR;
+    const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const unsigned limit = ((unsigned)(A.sh - 1)*A.sstep + (unsigned)A.sw*3u - 16u) & ~15u;      // LDSBOX: frames hold >= 16 bytes (host-checked)
+    __syncthreads();
+    {
+        const unsigned frame = blockIdx.x / tiles_pad;
+        int tx, ty;
+        const bool valid = tile_of_padded_id(blockIdx.x - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty);
+        if (valid) rp_prepare<LDSBOX>(xfs[frame], lk, s_tab, L, tx, ty, S, 0, 0, A.dh);
+        __syncthreads();
+        if (LDSBOX && valid) rl_issue(rl_box(S.box[0], A.sw, A.sh), A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[0], wave, lane);
+    }
+    unsigned it = 0;
+#pragma unroll 1
+    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x, it++) {
+        const unsigned vn = v + gridDim.x;
+        const int nb = (int)((it + 1) & 1);
+        bool nvalid = false;
+        unsigned fn = 0;
+        if (vn < n_work) {
+            fn = vn / tiles_pad;
+            int txn, tyn;
+            nvalid = tile_of_padded_id(vn - fn*tiles_pad, A.tiles_x, A.tiles_y, txn, tyn);
+            if (nvalid) rp_prepare<LDSBOX>(xfs[fn], lk, s_tab, L, txn, tyn, S, nb, (int)((it + 1) & 3), A.dh);
+        }
+        if (LDSBOX && threadIdx.x < 4) S.box[(it + 2) & 3][threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
+        if (LDSBOX) rl_wait();               // this wave's share of tile k's box has landed
+        lds_barrier();                       // barrier B
+        if (LDSBOX && nvalid) rl_issue(rl_box(S.box[(it + 1) & 3], A.sw, A.sh), A.src + (size_t)fn*A.sframe, A.sstep, limit, s_box[LDSBOX ? nb : 0], wave, lane);
+        const unsigned frame = v / tiles_pad;
+        int tx, ty;
+        const int buf = (int)(it & 1);
+        if (tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) {      // uniform
+            const int x0 = tx*RT + lx*PXT;
+            const Xf xf = xfs[frame];        // by value: the pass loop must not go back to memory for it
+            const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+            RlBox B; B.on = false; B.bx0 = B.by0 = 0; B.NXq = B.NYq = 0; B.xoffB = 0;
+            if (LDSBOX) B = rl_box(S.box[it & 3], A.sw, A.sh);
+            const int X0q = B.on ? B.bx0 << INTER_BITS : 0, Y0q = B.on ? B.by0 << INTER_BITS : 0;
+            const double mu = ROUND_MAGIC - (double)X0q, mv = ROUND_MAGIC - (double)Y0q;
+            const uint32_t* box = (const uint32_t*)s_box[LDSBOX ? buf : 0];
+            if (x0 < A.dw) {
+                RowC rc = row_consts(xf, ty*RT + ly);       // fills the row-independent members
+#pragma unroll GF_RL_UNROLL
+                for (int pass = 0; pass < RT_NPASS; pass++) {
+                    const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
+                    if (y >= A.dh) break;
+                    {
+                        const double di = (double)y;
+                        rc.rx = __dadd_rn(__dmul_rn(di, xf.iR[1]), xf.iR[2]);
+                        rc.ry = __dadd_rn(__dmul_rn(di, xf.iR[4]), xf.iR[5]);
+                        rc.rw = __dadd_rn(__dmul_rn(di, xf.iR[7]), xf.iR[8]);
+                    }
+                    int iu[PXT], iv[PXT], px[PXT][3];
+                    unsigned keep = 0;
+                    bool done = false;
+                    if (S.ok[buf][rr]) {
+                        rp_coords(rc, S.C[buf][rr], L.z, x0, mu, mv, iu, iv);
+                        if (LDSBOX) {
+                            const unsigned rumax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
+                            const unsigned rvmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
+                            if (rumax < B.NXq && rvmax < B.NYq) {
+#pragma unroll
+                                for (int e = 0; e < PXT; e++) interp_u8_raw<HI16>(box, (unsigned)iu[e], (unsigned)iv[e], B.xoffB, px[e]);
+                                done = true;
+                            } else {
+#pragma unroll
+                                for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
+                            }
+                        }
+                    } else {
+                        coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+                    }
+                    if (!done) keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
+                    uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+                    store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+                }
+            }
+        }
+        lds_barrier();                       // barrier A
+    }
+}
+
+// K2 with RP coordinates (CV_16SC2 maps): one 64 x 64 tile per workgroup.
+__global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, const double* __restrict__ lens, const double* __restrict__ rp_tab, int w, int h,
+                                                            uint8_t* map1, size_t m1step, uint8_t* map2, size_t m2step)
+{
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
+    __shared__ RpShared S;
+    load_lens_table(lens, s_tab);
+    const RpLane L = rp_lane_consts(rp_tab, (int)threadIdx.x, S);
+    const int lx = threadIdx.x & (RT_TPR - 1), ly = threadIdx.x / RT_TPR;
+    const int tx = blockIdx.x, ty = blockIdx.y;
+    __syncthreads();
+    rp_prepare<false>(xf, lk, s_tab, L, tx, ty, S, 0, 0, h);
+    __syncthreads();
+    const int x0 = tx*RT + lx*PXT;
+    if (x0 >= w) return;
+#pragma unroll 1
+    for (int pass = 0; pass < RT_NPASS; pass++) {
+        const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
+        if (y >= h) break;
+        const RowC rc = row_consts(xf, y);
+        int iu[PXT], iv[PXT];
+        if (S.ok[0][rr]) rp_coords(rc, S.C[0][rr], L.z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+        else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+        int16_t* m1 = (int16_t*)(map1 + (size_t)y*m1step);
+        uint16_t* m2 = (uint16_t*)(map2 + (size_t)y*m2step);
+#pragma unroll
+        for (int e = 0; e < PXT; e++)
+            if (x0 + e < w) {
+                *(uint32_t*)(m1 + 2*(x0 + e)) = (uint32_t)(uint16_t)(iu[e] >> INTER_BITS) | ((uint32_t)(uint16_t)(iv[e] >> INTER_BITS) << 16);   // (short) cast wraps (Q1)
+                m2[x0 + e] = (uint16_t)((iv[e] & 31)*32 + (iu[e] & 31));
+            }
     }
 }
 
@@ -1685,11 +2089,17 @@ GF_API int gf_ctx_create(int device, void** ctx)
     std::call_once(g_cubic_once, build_cubic_host);
     Ctx* c = new (std::nothrow) Ctx();
     if (!c) return fail(GF_ERR_HIP, "%s: out of host memory", "gf_ctx_create");
-    c->device = device; c->cubic_tab = nullptr; c->tick = 0; c->n_cu = 0;
+    c->device = device; c->cubic_tab = nullptr; c->rp_tab = nullptr; c->tick = 0; c->n_cu = 0; c->k1_mode = g_k1_mode;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
     for (int i = 0; i < LENS_SLOTS; i++) { c->lens[i].valid = false; c->lens[i].dev = nullptr; c->lens[i].host = nullptr; c->lens[i].last_use = 0; }
     hipError_t e = hipMalloc((void**)&c->cubic_tab, sizeof g_cubic_host);
     if (e == hipSuccess) e = hipMemcpy(c->cubic_tab, g_cubic_host, sizeof g_cubic_host, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->rp_tab, RP_TAB_DOUBLES*sizeof(double));
+    if (e == hipSuccess) {
+        double t[RP_TAB_DOUBLES];
+        build_rp_table(t);
+        e = hipMemcpy(c->rp_tab, t, sizeof t, hipMemcpyHostToDevice);
+    }
     for (int i = 0; i < LENS_SLOTS && e == hipSuccess; i++) {
         e = hipMalloc((void**)&c->lens[i].dev, LENS_DOUBLES*sizeof(double));
         if (e == hipSuccess) e = hipHostMalloc((void**)&c->lens[i].host, LENS_DOUBLES*sizeof(double), hipHostMallocDefault);
@@ -1702,11 +2112,20 @@ GF_API int gf_ctx_create(int device, void** ctx)
     return GF_OK;
 }
 
+GF_API int gf_ctx_set_kernel_mode(void* ctx, int mode)
+{
+    if (!ctx) return fail(GF_ERR_INVALID_ARG, "%s: null ctx", "gf_ctx_set_kernel_mode");
+    if (mode != GF_KERNEL_DIRECT && mode != GF_KERNEL_RP && mode != GF_KERNEL_RL) return fail(GF_ERR_INVALID_ARG, "gf_ctx_set_kernel_mode: unknown mode %s%lld", "", mode);
+    ((Ctx*)ctx)->k1_mode = mode;
+    return GF_OK;
+}
+
 GF_API int gf_ctx_destroy(void* ctx)
 {
     if (!ctx) return GF_OK;
     Ctx* c = (Ctx*)ctx;
     if (c->cubic_tab) (void)hipFree(c->cubic_tab);
+    if (c->rp_tab) (void)hipFree(c->rp_tab);
     for (int i = 0; i < LENS_SLOTS; i++) {
         if (c->lens[i].dev) (void)hipFree(c->lens[i].dev);
         if (c->lens[i].host) (void)hipHostFree(c->lens[i].host);
@@ -1751,7 +2170,9 @@ static int maps_common(void* ctx, const double* D, const gf_frame_xform* xf, int
     const double* lens; LensK lk;
     int rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
     dim3 grid((w + 63)/64, (h + 63)/64);
-    if (fixed) hipLaunchKernelGGL(k_fisheye_maps<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
+    if (fixed && c->k1_mode != GF_KERNEL_DIRECT) hipLaunchKernelGGL(k_fisheye_maps_rp, dim3((w + RT - 1)/RT, (h + RT - 1)/RT), dim3(BLOCK), 0, (hipStream_t)stream,
+                                                    to_xf(xf), lk, lens, (const double*)c->rp_tab, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
+    else if (fixed) hipLaunchKernelGGL(k_fisheye_maps<true>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
     else       hipLaunchKernelGGL(k_fisheye_maps<false>, grid, dim3(BLOCK), 0, (hipStream_t)stream, to_xf(xf), lk, lens, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
     HIP_TRY(hipGetLastError());
     return GF_OK;
@@ -1901,6 +2322,34 @@ static int launch_fused(Ctx* c, bool lds_tiles, int depth, const void* src, int 
             else LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_TRANSPARENT, 1);
         }
 #undef LAUNCH_LDS
+    } else if (c->k1_mode != GF_KERNEL_DIRECT) {
+        // RP coordinates on 64 x 64 tiles; u8 frames with 16-byte aligned base, row pitch and frame stride also stage their
+        // source taps through LDS (mode 2, the default)
+        A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
+        const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
+        const unsigned long long n_work = (unsigned long long)tiles_pad*(unsigned)n_frames;
+        if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many tiles in one call (%lld)", "gf_undistort_rotate_c3", (long long)n_work);
+        const bool ldsbox = c->k1_mode == GF_KERNEL_RL && depth == GF_DEPTH_U8 && ((uintptr_t)src & 15) == 0 && (sstep & 15) == 0 && (sframe & 15) == 0 &&
+                            (size_t)(sh - 1)*sstep + (size_t)sw*3 >= 32;
+        unsigned blocks = (unsigned)c->n_cu*(ldsbox ? WG_PER_CU_RL : WG_PER_CU_RP) & ~(unsigned)(NXCD - 1);
+        if (blocks == 0) blocks = NXCD;
+        if (blocks > n_work) blocks = (unsigned)n_work;
+        dim3 grid(blocks, 1);
+#define LAUNCH_RP(DEPTH_, BORDER_, BOX_) hipLaunchKernelGGL((k_undistort_rotate_rp<DEPTH_, BORDER_, BOX_>), grid, dim3(BLOCK), 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work)
+        if (depth == GF_DEPTH_U8 && ldsbox) {
+            if (border == GF_BORDER_CONSTANT) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_CONSTANT, true);
+            else if (border == GF_BORDER_REPLICATE) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_REPLICATE, true);
+            else LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_TRANSPARENT, true);
+        } else if (depth == GF_DEPTH_U8) {
+            if (border == GF_BORDER_CONSTANT) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_CONSTANT, false);
+            else if (border == GF_BORDER_REPLICATE) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_REPLICATE, false);
+            else LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_TRANSPARENT, false);
+        } else {
+            if (border == GF_BORDER_CONSTANT) LAUNCH_RP(GF_DEPTH_U16, GF_BORDER_CONSTANT, false);
+            else if (border == GF_BORDER_REPLICATE) LAUNCH_RP(GF_DEPTH_U16, GF_BORDER_REPLICATE, false);
+            else LAUNCH_RP(GF_DEPTH_U16, GF_BORDER_TRANSPARENT, false);
+        }
+#undef LAUNCH_RP
     } else {
         // persistent grid: WG_PER_CU workgroups per CU (what the kernel's register and LDS use allows), a multiple of 8
         const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);

@@ -61,6 +61,17 @@ GF_API const char* gf_last_error(void);
 GF_API int gf_ctx_create(int device, void** ctx);
 GF_API int gf_ctx_destroy(void* ctx);
 
+/* Kernel variant used by gf_undistort_rotate_c3 and gf_fisheye_maps_16sc2 of this context (no counterpart in the reference:
+ * an A/B switch; results are the same to the tolerance documented in DESIGN.md, and fused == maps + remap bit for bit in
+ * every mode).  DIRECT: per-pixel lens-table coordinates, taps gathered from the frame (default).  RP: coordinates from
+ * per-row polynomials on 64 x 64 tiles.  RL: RP coordinates + source taps staged through LDS by LDS-DMA (u8 frames with
+ * 16-byte aligned base / pitch / frame stride; other inputs run as RP).  Not thread-safe against concurrent launches on
+ * the same context. */
+#define GF_KERNEL_DIRECT 0
+#define GF_KERNEL_RP     1
+#define GF_KERNEL_RL     2
+GF_API int gf_ctx_set_kernel_mode(void* ctx, int mode);
+
 /* Per-frame transform consumed by the kernels: everything cv2.fisheye.initUndistortRectifyMap derives
  * from (K, R, P) before its pixel loop: iR = (P[:, :3] * R)^-1, f/c = focal length/centre of K.  The lens distortion
  * coefficients D = (k1..k4) belong to the lens, not the frame: the calls below take them as 4 HOST doubles and keep a
