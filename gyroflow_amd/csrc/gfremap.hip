@@ -6,19 +6,21 @@
 //   nonlinear_stretch.py:130    apply_stretch               -> cv2.remap(INTER_CUBIC)
 //
 // Design (DESIGN.md has the numbers):
-//  * The kernels are VALU-issue bound, not HBM bound, unless the per-pixel instruction count is cut hard, so the
-//    lens model is evaluated as  u = fx * (X/W) * S(t) + cx,  t = (X^2+Y^2)/W^2,  S(t) = theta_d(atan sqrt t)/sqrt t,
-//    with S read from a per-lens table of degree-5 polynomials (512 pieces, geometric in 1+t, 24 KB in LDS, relative
-//    error < 1e-14) and 1/W from v_rcp_f64 + one Newton step: 24 f64 ops per pixel instead of ~110 (atan, sqrt and
-//    three IEEE divisions).  Pixels whose ray leaves the table (more than ~86 degrees off axis, or behind the camera)
+//  * The fused kernel is bound by the vector-memory return path and by VALU issue, not by HBM, so the lens model is evaluated
+//    as  u = fx * (X/W) * S(t) + cx,  t = (X^2+Y^2)/W^2,  S(t) = theta_d(atan sqrt t)/sqrt t,  with S read from a per-lens
+//    table of degree-6 polynomials (256 pieces, geometric in 1+t, 16 KB in LDS, relative error < 2e-14) and 1/W from
+//    v_rcp_f64 + one Newton step.  Pixels whose ray leaves the table (more than ~86 degrees off axis, or behind the camera)
 //    take the exact formula.
 //  * u8 bilinear taps use v_dot4_u32_u8 on the raw loaded dwords (no byte unpacking): a horizontal pass with the
 //    5-bit x weights, then a vertical 24-bit mad pass -- the same integers as OpenCV's Q15 table.
 //  * One thread produces PXT=4 horizontally adjacent output pixels (12 B of u8 BGR = one dwordx3 store; a wave64
 //    writes two 384-B row segments = whole 128-B lines); a 256-thread workgroup covers a 128x32 output tile in four
-//    passes of 8 rows; blockIdx.y is the frame.  The fixed-point map (INTER_BITS=5) lives in registers only.
-//  * Source taps are gathered through L1/L2 with unaligned dword loads; workgroups are dealt to XCDs in contiguous
+//    passes of 8 rows; workgroups are persistent and walk (frame, tile) work items.  The fixed-point map (INTER_BITS=5)
+//    lives in registers only.
+//  * Source taps are gathered through L1/L2 with unaligned 8-byte loads; workgroups are dealt to XCDs in contiguous
 //    bands of tile rows so that each XCD's L2 sees one horizontal band of the source frame.
+//  * Two alternative variants of the fused kernel (gf_ctx_set_kernel_mode) trade that design's costs differently: RP takes
+//    the coordinates from per-row polynomials, RL additionally stages the source box of a tile in LDS by LDS-DMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -49,7 +51,6 @@ constexpr int TPR = TILE_W/PXT;               // threads per tile row
 constexpr int PASS_H = BLOCK/TPR;             // rows per pass
 static_assert(TILE_W % PXT == 0 && BLOCK % TPR == 0 && TILE_H % PASS_H == 0 && (TPR & (TPR - 1)) == 0, "tile shape");
 constexpr int NXCD = 8;
-const unsigned WG_PER_CU_LDS = getenv("GF_WG_PER_CU_LDS") ? (unsigned)atoi(getenv("GF_WG_PER_CU_LDS")) : 3u;
 const unsigned WG_PER_CU = getenv("GF_WG_PER_CU") ? (unsigned)atoi(getenv("GF_WG_PER_CU")) : 24u;  // persistent fused kernel: workgroups per CU (5 are resident; the surplus evens out the tail, measured +4 %)
 
 // lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave; per piece the centre q_mid and the
@@ -72,24 +73,21 @@ constexpr int RT_TPR = RT/PXT;                          // 16 threads per tile r
 constexpr int RT_RPP = BLOCK/RT_TPR;                    // 16 rows per pass
 constexpr int RT_NPASS = RT/RT_RPP;                     // 4 passes
 constexpr int RP_N = 8;
-constexpr int RP_TAB_DOUBLES = RP_N*RP_N + RP_N;        // node values -> monomial coefficients (row-major), then the nodes
+constexpr int RP_TAB_DOUBLES = RP_N*RP_N + RP_N + RT*RP_N;  // inverse Vandermonde matrix (row-major), the nodes, row weights [RT][RP_N]
 constexpr double RP_HALF = RT/2.0;                      // the nodes span [-0.5, RT - 0.5]
 constexpr double RP_GUARD = 8.0;                        // singularities of G at least this many half tiles away
 // RL (LDS-staged source box of the RP kernel, u8): raw source rows at a fixed pitch, four rows per LDS-DMA instruction
 constexpr int RL_PITCH = 256;                           // bytes per box row in LDS (16 lanes x 16 bytes)
-#ifndef GF_RL_TAB_GLOBAL
-#define GF_RL_TAB_GLOBAL 1
+#ifndef GF_RL_WGS
+#define GF_RL_WGS 2              /* workgroups per CU the LDS budget below is sized for */
 #endif
 #ifndef GF_RL_ROWS
-#define GF_RL_ROWS (GF_RL_TAB_GLOBAL ? 84 : 104)
+#define GF_RL_ROWS (GF_RL_WGS >= 3 ? 68 : 120)
 #endif
-constexpr int RL_ROWS = GF_RL_ROWS;                     // rows per box buffer (21 KB; two buffers)
+constexpr int RL_ROWS = GF_RL_ROWS;                     // rows per box buffer (two buffers)
 static_assert(RL_ROWS % 4 == 0, "four rows per LDS-DMA instruction");
 
 thread_local char g_err[512] = "";
-// A/B switch (tools/kbench): the LDS-staged variant of the fused kernel is correct but, as measured on MI355X, ~20 %
-// slower than the direct-gather kernel (more VALU work per pixel, three barriers per tile), so it is opt-in.
-const bool g_use_lds_tiles = getenv("GF_USE_LDS_TILES") != nullptr;
 // Kernel variants of the fused kernel and the CV_16SC2 map kernel (gf_ctx_set_kernel_mode; the environment variable GF_K1
 // = direct | rp | rl sets the default of new contexts): direct = per-pixel lens-table coordinates (kernel v4, the fastest
 // as measured on MI355X and the default), rp = RP coordinates (per-row polynomials) with taps gathered from the frame,
@@ -259,6 +257,15 @@ void build_rp_table(double* out)
     for (int a = 0; a < RP_N; a++)
         for (int n = 0; n < RP_N; n++) out[a*RP_N + n] = (double)A[a][RP_N + n];
     for (int n = 0; n < RP_N; n++) out[RP_N*RP_N + n] = (double)z[n];
+    // row weights: Lagrange basis polynomial m (nodes z) at tile row r, i.e. at (r - (RP_HALF - 0.5))/RP_HALF
+    for (int r = 0; r < RT; r++) {
+        const long double eta = ((long double)r - ((long double)RP_HALF - 0.5L))/(long double)RP_HALF;
+        for (int m = 0; m < RP_N; m++) {
+            long double l = 1;
+            for (int k = 0; k < RP_N; k++) if (k != m) l *= (eta - z[k])/(z[m] - z[k]);
+            out[RP_N*RP_N + RP_N + r*RP_N + m] = (double)l;
+        }
+    }
 }
 
 // the kernel's table lookup, restated for the host (gf_lens_scale_host; CPU tests check it against long double)
@@ -589,38 +596,6 @@ __device__ __forceinline__ void interp_u8_interior(const uint8_t* __restrict__ b
     bilin_u8_rows<HI16>(t.a, t.b, iu, iv, out);
 }
 
-// LDS-staged taps.  The workgroup's source box is held in LDS with one padded pixel per dword (u8: B G R x) or per
-// 8 bytes (u16: B G R x as halfwords), so the two taps of a source row are adjacent, aligned LDS words (unaligned LDS
-// reads are serialised by the hardware: SQ_LDS_UNALIGNED_STALL).  Positions are handled relative to the box origin in
-// Q5 units: ru = iu - X0, rv = iv - Y0; tap position (ru >> 5, rv >> 5) sits at pixel index (rv >> 5)*pitch + (ru >> 5) + xoff.
-typedef const __attribute__((address_space(3))) uint32_t* lds_u32;
-struct LdsBox {
-    lds_u32 p;
-    unsigned X0, Y0;      // Q5 origin (first tap position held, << 5)
-    unsigned NX, NY;      // Q5 extents: tap positions with ru < NX and rv < NY are held (with their right/bottom neighbours)
-    unsigned pitch;       // pixels per LDS row
-    unsigned xoff;        // pixel index of the first tap column within an LDS row
-    bool on;
-};
-
-template <bool HI16>
-__device__ __forceinline__ void interp_u8_box(const LdsBox& L, unsigned ru, unsigned rv, int* out)
-{
-    const unsigned idx = __umul24(rv >> 5, L.pitch) + (ru >> 5) + L.xoff;
-    const uint32_t p00 = L.p[idx], p01 = L.p[idx + 1], p10 = L.p[idx + L.pitch], p11 = L.p[idx + L.pitch + 1];
-    // v_perm_b32: [B0 B1 G0 G1] and [R0 R1 0 0] of each source row, then three dot4 per row with (32-fx, fx)
-    const uint32_t tA = __builtin_amdgcn_perm(p01, p00, 0x05010400u), tB = __builtin_amdgcn_perm(p01, p00, 0x0c0c0602u);
-    const uint32_t bA = __builtin_amdgcn_perm(p11, p10, 0x05010400u), bB = __builtin_amdgcn_perm(p11, p10, 0x0c0c0602u);
-    const unsigned wlo = __umul24(ru & 31u, 0xFFu) + 32u, whi = wlo << 16;     // (32 - fx) | fx << 8
-    const unsigned wy1 = (rv << 6) & 0x7C0u, wy0 = 2048u - wy1;                 // 64 fy, 64 (32 - fy): result lands in bits 16..23
-    const unsigned tBv = __builtin_amdgcn_udot4(tA, wlo, 0u, false), tGv = __builtin_amdgcn_udot4(tA, whi, 0u, false), tRv = __builtin_amdgcn_udot4(tB, wlo, 0u, false);
-    const unsigned bBv = __builtin_amdgcn_udot4(bA, wlo, 0u, false), bGv = __builtin_amdgcn_udot4(bA, whi, 0u, false), bRv = __builtin_amdgcn_udot4(bB, wlo, 0u, false);
-    const unsigned rB = umad24(bBv, wy1, umad24(tBv, wy0, 32768u));
-    const unsigned rG = umad24(bGv, wy1, umad24(tGv, wy0, 32768u));
-    const unsigned rR = umad24(bRv, wy1, umad24(tRv, wy0, 32768u));
-    out[0] = (int)(HI16 ? rB : rB >> 16); out[1] = (int)(HI16 ? rG : rG >> 16); out[2] = (int)(HI16 ? rR : rR >> 16);
-}
-
 // u16 taps: OpenCV's float path -- float32 weights, ((p00 w00 + p01 w01) + p10 w10) + p11 w11 with every product and
 // sum rounded (no FMA), cvRound, saturate.  r0/r1 = the 12 bytes (two pixels) of the upper/lower source row.
 __device__ __forceinline__ void bilin_u16_vals(const unsigned* p00, const unsigned* p01, const unsigned* p10, const unsigned* p11,
@@ -644,18 +619,6 @@ __device__ __forceinline__ void bilin_u16_float(const U16x6& r0, const U16x6& r1
     const unsigned p00[3] = {r0.a & 0xffff, r0.a >> 16, r0.b & 0xffff}, p01[3] = {r0.b >> 16, r0.c & 0xffff, r0.c >> 16};
     const unsigned p10[3] = {r1.a & 0xffff, r1.a >> 16, r1.b & 0xffff}, p11[3] = {r1.b >> 16, r1.c & 0xffff, r1.c >> 16};
     bilin_u16_vals(p00, p01, p10, p11, fx, fy, out);
-}
-
-__device__ __forceinline__ void interp_u16_box(const LdsBox& L, unsigned ru, unsigned rv, int* out)
-{
-    typedef unsigned int u2_t __attribute__((ext_vector_type(2)));
-    typedef const __attribute__((address_space(3))) u2_t* lds_u2;
-    lds_u2 P = (lds_u2)L.p;
-    const unsigned idx = __umul24(rv >> 5, L.pitch) + (ru >> 5) + L.xoff;
-    const u2_t a0 = P[idx], a1 = P[idx + 1], b0 = P[idx + L.pitch], b1 = P[idx + L.pitch + 1];
-    const unsigned p00[3] = {a0.x & 0xffff, a0.x >> 16, a0.y & 0xffff}, p01[3] = {a1.x & 0xffff, a1.x >> 16, a1.y & 0xffff};
-    const unsigned p10[3] = {b0.x & 0xffff, b0.x >> 16, b0.y & 0xffff}, p11[3] = {b1.x & 0xffff, b1.x >> 16, b1.y & 0xffff};
-    bilin_u16_vals(p00, p01, p10, p11, (int)(ru & 31u), (int)(rv & 31u), out);
 }
 
 struct TapsU16 { U16x6 a, b; };             // the 12 bytes (two pixels) at (sx, sy) and at (sx, sy+1)
@@ -689,26 +652,11 @@ template <> struct TapsT<GF_DEPTH_U16> { typedef TapsU16 T; };
 // runs on the unwrapped integers and only the general path applies the wrap.  Returns the keep mask.
 // HI16 (u8 only): pixel values are returned in bits 16..23 of px (other bits undefined); store_px<DEPTH, true> expects that.
 template <int DEPTH, int BORDER, bool HI16 = false>
-__device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const int* iv, const int* cval, int (*px)[3],
-                                           const LdsBox L = LdsBox{nullptr, 0, 0, 0, 0, 0, 0, false})
+__device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const int* iv, const int* cval, int (*px)[3])
 {
     static_assert(PXT == 4, "interior test is written for 4 pixels");
     static_assert(!HI16 || DEPTH == GF_DEPTH_U8, "HI16 is a u8 representation");
     unsigned keep = 0;
-    if (L.on) {
-        unsigned ru[PXT], rv[PXT];
-#pragma unroll
-        for (int i = 0; i < PXT; i++) { ru[i] = (unsigned)iu[i] - L.X0; rv[i] = (unsigned)iv[i] - L.Y0; }
-        const unsigned rumax = max(max(ru[0], ru[1]), max(ru[2], ru[3])), rvmax = max(max(rv[0], rv[1]), max(rv[2], rv[3]));
-        if (rumax < L.NX && rvmax < L.NY) {
-#pragma unroll
-            for (int i = 0; i < PXT; i++) {
-                if constexpr (DEPTH == GF_DEPTH_U8) interp_u8_box<HI16>(L, ru[i], rv[i], px[i]);
-                else                                interp_u16_box(L, ru[i], rv[i], px[i]);
-            }
-            return 0;
-        }
-    }
     // u8 taps are fetched with 8-byte loads (2 spare bytes): keeping the last source column pair (sx == w-2) out of the
     // fast path means those spare bytes are always inside the row, never past the end of the frame.
     // Interior: 0 <= sx < w1 and 0 <= sy < h1 for all four pixels, tested on the Q5 values (negative ones are huge as unsigned).
@@ -935,108 +883,114 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
 
 // ---------------------------------------------------------------------------------------------
 // RP: coordinates from per-row polynomials.
-// 32u = fx32 * _x * G + cx32 and 32v = fy32 * _y * G + cy32 with G = S(t) / _w.  _x, _y are linear in the column j, and
-// along an output row G is analytic in j with its nearest singularities (q = 1 + t = 0 and _w = 0) |P| / |column step
-// of iR| pixels away from a pixel with ray P = (_x, _y, _w) -- about one focal length of the output camera.  On a
-// 64-pixel row segment whose half width is at most 1/8 of that distance the polynomial through 8 Chebyshev nodes is
-// accurate to 2e-10 relative at worst (Bernstein ellipse parameter >= 16) and to rounding error for the BASELINE
-// configurations (parameter 110 for a 4K frame, 55 for 1080p: 55^-8 = 1e-14), the same class of error as the lens table
-// itself.  Per 64 x 64 tile every thread evaluates G twice through the lens table -- thread t at node t % 8 of tile rows
-// t / 8 and 32 + t / 8 -- and converts node values to one monomial coefficient of those rows (an 8-term dot product with a
-// row of the inverse Vandermonde matrix, build_rp_table; the eight nodes of a row sit in eight adjacent lanes of one
-// wave, so the exchange needs no barrier).  The tile's pixels then cost a degree-7 Horner evaluation (7 fma) instead of
-// the reciprocal, the table lookup and the degree-6 piece: 15 f64 operations per pixel instead of 31.
-// A row with a node that fails a check (ray behind the camera or outside the table, singularity too close, absurd focal
-// data) takes the per-pixel path (coord_q5x4).  k_undistort_rotate_rp and k_fisheye_maps_rp use the same functions on the
-// same tile grid, so their coordinates are identical bit for bit.
-static_assert(BLOCK/RP_N*2 == RT && RP_N == 8 && BLOCK == 256, "two node evaluations per thread and tile");
+// 32u = fx32 * _x * G + cx32 and 32v = fy32 * _y * G + cy32 with G = S(t) / _w.  _x, _y are linear in the column j, and G is
+// analytic in the output position with its nearest singularities (q = 1 + t = 0 and _w = 0) |P| / |step of iR| pixels away
+// from a pixel with ray P = (_x, _y, _w) -- about one focal length of the output camera.  On a 64 x 64 tile whose half width
+// is at most 1/8 of that distance the tensor-product interpolant through 8 x 8 Chebyshev nodes is accurate to 2e-10
+// relative at worst (Bernstein ellipse parameter >= 16) and to rounding error for the BASELINE configurations (parameter
+// 110 for a 4K frame, 55 for 1080p: 55^-8 = 1e-14), the same class of error as the lens table itself.  Per tile
+//   rp_nodes: one wave evaluates G at the 64 nodes through the lens table (lane = node column a + 8 * node row m), checks
+//             every node (ray in front of the camera and inside the table, singularities far enough, sane focal data) and
+//             turns each node row into monomial coefficients in z = (j - centre)/32 (an 8-term dot product with a row of
+//             the inverse Vandermonde matrix; the eight nodes of a row sit in eight adjacent lanes, so no barrier);
+//   rp_rows:  the coefficient vector of every tile row = the node rows' vectors weighted with the Lagrange weights of that
+//             row (8 fma per coefficient);
+//   rp_coords: a pixel costs a degree-7 Horner evaluation (7 fma) instead of the reciprocal, the table lookup and the
+//             degree-6 piece: 15 f64 operations instead of 31.
+// A tile with a node that fails a check takes the per-pixel path (coord_q5x4).  k_undistort_rotate_rp, k_undistort_rotate_rl
+// and k_fisheye_maps_rp use the same functions on the same tile grid, so their coordinates are identical bit for bit.
+static_assert(RP_N == 8 && RT == 64 && BLOCK == 256, "lane <-> node and thread <-> row mappings below");
 #ifndef GF_RP_WAVES
 #define GF_RP_WAVES 2
 #endif
-#ifndef GF_RL_UNROLL
-#define GF_RL_UNROLL 1
-#endif
 
+struct RpConst {                    // LDS copies of build_rp_table's constants
+    double M[RP_N][RP_N];           // inverse Vandermonde matrix
+    double Ly[RT][RP_N];            // Lagrange weights of the tile rows
+};
 struct RpShared {
-    double U[BLOCK/64][8][RP_N];    // wave-private: G at the nodes of the eight rows a wave evaluates at a time
+    RpConst K;
+    double U[RP_N][RP_N];           // scratch of the wave that runs rp_nodes
+    double C2[2][RP_N][RP_N];       // [buffer][node row][power]
     double C[2][RT][RP_N];          // [buffer][tile row][power]: monomial coefficients in z
-    double M[RP_N][RP_N];           // inverse Vandermonde matrix (rp_tab)
-    int ok[2][RT];                  // the row may use its polynomial
-    int box[4][4];                  // [slot][min u, max u, min v, max v]: integer source positions of the tile's nodes
-};
-struct RpLane {
-    double z[PXT];                  // z of the thread's four pixel columns (the same in every tile)
-    double node_off;                // pixel offset of node a within the tile
-    int a, rsub;                    // this thread's node and row (rows rsub and 32 + rsub) in rp_prepare
+    int ok[4];                      // [slot]: the tile may use its polynomials
 };
 
-// Also copies the matrix into LDS and resets the box slots; the caller's next barrier orders both before their first use.
-__device__ __forceinline__ RpLane rp_lane_consts(const double* __restrict__ rp_tab, int tid, RpShared& S)
+// Copies the constants into LDS (the caller's next barrier orders that before their first use).
+__device__ __forceinline__ void rp_load_consts(const double* __restrict__ rp_tab, RpConst& K, int tid, int nthreads)
 {
-    RpLane L;
-    L.a = tid & (RP_N - 1); L.rsub = tid / RP_N;
-    if (tid < RP_N*RP_N) (&S.M[0][0])[tid] = rp_tab[tid];
-    if (tid < 16) (&S.box[0][0])[tid] = (tid & 1) ? INT_MIN : INT_MAX;
-    L.node_off = (RP_HALF - 0.5) + RP_HALF*rp_tab[RP_N*RP_N + L.a];
-    const int lx = tid & (RT_TPR - 1);
-#pragma unroll
-    for (int e = 0; e < PXT; e++) L.z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);      // exact
-    return L;
+    for (int i = tid; i < RP_N*RP_N; i += nthreads) (&K.M[0][0])[i] = rp_tab[i];
+    for (int i = tid; i < RT*RP_N; i += nthreads) (&K.Ly[0][0])[i] = rp_tab[RP_N*RP_N + RP_N + i];
 }
+__device__ __forceinline__ double rp_node_off(const double* __restrict__ rp_tab, int n) { return (RP_HALF - 0.5) + RP_HALF*rp_tab[RP_N*RP_N + n]; }
 
-// All threads: coefficients and row flags of tile (tx, ty) -> S.C[buf], S.ok[buf]; with BOX also the extent of the
-// tile's rim nodes' source positions -> S.box[slot].
+// One wave, all 64 lanes: lane = a + 8 m evaluates node (column a, row m) of tile (tx, ty); offx / offy = rp_node_off(a / m).
+// Results: C2[m][a] (coefficient a of node row m), *okflag (every node passed), and with BOX the source positions of the
+// tile's rim nodes merged into boxslot[0..3] (min u, max u, min v, max v).
 template <bool BOX>
-__device__ __forceinline__ void rp_prepare(const Xf& xf, const LensK& lk, const double2* __restrict__ tab, const RpLane& L, int tx, int ty,
-                                           RpShared& S, int buf, int slot, int dh)
+__device__ __forceinline__ void rp_nodes(const Xf& xf, const LensK& lk, const double2* __restrict__ tab, double offx, double offy, int a, int m,
+                                         int tx, int ty, double (*U)[RP_N], const RpConst& K, double (*C2)[RP_N], int* okflag, int* boxslot)
 {
     const unsigned hi_limit = lens_hi_limit(xf, lk);
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    const double dj = (double)(tx*RT) + L.node_off;
-    const double G2 = (RP_GUARD*RP_HALF)*(RP_GUARD*RP_HALF);
-#pragma unroll 1
-    for (int half = 0; half < 2; half++) {
-        const int r = half*(RT/2) + L.rsub;
-        const RowC rc = row_consts(xf, ty*RT + r);
-        const double X = __fma_rn(dj, rc.ax, rc.rx), Y = __fma_rn(dj, rc.ay, rc.ry), W = __fma_rn(dj, rc.aw, rc.rw);
-        double iw = __builtin_amdgcn_rcp(W);
-        iw = __fma_rn(__fma_rn(-W, iw, 1.0), iw, iw);
-        const double x = X*iw, y = Y*iw;
-        const double q = __fma_rn(x, x, __fma_rn(y, y, 1.0));
-        const unsigned qhi = (unsigned)__double2hiint(q);
-        const unsigned off = (qhi >> (20 - LENS_SUB_BITS - 6)) & ((unsigned)(LENS_N - 1) << 6);
-        const double2* c = (const double2*)((const char*)tab + off);
-        const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-        const double dz = q - c0.x;
-        double Sc = __fma_rn(c3.y, dz, c3.x);
-        Sc = __fma_rn(Sc, dz, c2.y); Sc = __fma_rn(Sc, dz, c2.x); Sc = __fma_rn(Sc, dz, c1.y); Sc = __fma_rn(Sc, dz, c1.x);
-        Sc = __fma_rn(Sc, dz, c0.y);
-        const double G = Sc*iw;
-        // distance to the nearest singularity of G along the row, in pixels: |P| / |step| (q = 0) and _w / |step of _w| (_w = 0)
-        const double a2 = rc.ax*rc.ax + rc.ay*rc.ay + rc.aw*rc.aw, W2 = W*W;
-        const bool ok = lens_ok(W, qhi, hi_limit) && W2*q >= G2*a2 && W2 >= G2*(rc.aw*rc.aw);
-        const unsigned long long mask = __ballot(ok);                  // a row's RP_N nodes sit in adjacent lanes
-        const bool row_ok = ((mask >> (lane & ~(RP_N - 1))) & ((1u << RP_N) - 1)) == ((1u << RP_N) - 1);
-        if (L.a == 0) S.ok[buf][r] = row_ok ? 1 : 0;
-        // Box: the tile's corner nodes and the end nodes of its two middle rows (8 samples; LDS atomics from many lanes to
-        // one address are serialised and cost more than the tile itself).  The margin of rl_box covers the bulge between them.
-        if (BOX && row_ok && (L.a == 0 || L.a == RP_N - 1) && (L.rsub == 0 || L.rsub == RT/2 - 1)) {
-            const int su = __double2loint(__fma_rn(X*G, rc.fx32, rc.cx32) + ROUND_MAGIC) >> INTER_BITS;
-            const int sv = __double2loint(__fma_rn(Y*G, rc.fy32, rc.cy32) + ROUND_MAGIC) >> INTER_BITS;
-            atomicMin(&S.box[slot][0], su); atomicMax(&S.box[slot][1], su); atomicMin(&S.box[slot][2], sv); atomicMax(&S.box[slot][3], sv);
-        }
-        // node values -> coefficient L.a of row r, through the wave's scratch rows (LDS operations of one wave execute in
-        // program order; the empty asm statements keep the compiler from moving the reads above the writes and back)
-        S.U[wave][L.rsub & 7][L.a] = G;
-        asm volatile("" ::: "memory");
-        const double2* u = (const double2*)S.U[wave][L.rsub & 7];
-        const double2* m = (const double2*)S.M[L.a];
-        const double2 u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3], m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3];
-        asm volatile("" ::: "memory");
-        double cf = m0.x*u0.x;
-        cf = __fma_rn(m0.y, u0.y, cf); cf = __fma_rn(m1.x, u1.x, cf); cf = __fma_rn(m1.y, u1.y, cf);
-        cf = __fma_rn(m2.x, u2.x, cf); cf = __fma_rn(m2.y, u2.y, cf); cf = __fma_rn(m3.x, u3.x, cf); cf = __fma_rn(m3.y, u3.y, cf);
-        S.C[buf][r][L.a] = cf;
+    const double dj = (double)(tx*RT) + offx, di = (double)(ty*RT) + offy;
+    const double rx = __dadd_rn(__dmul_rn(di, xf.iR[1]), xf.iR[2]), ry = __dadd_rn(__dmul_rn(di, xf.iR[4]), xf.iR[5]);
+    const double rw = __dadd_rn(__dmul_rn(di, xf.iR[7]), xf.iR[8]);
+    const double X = __fma_rn(dj, xf.iR[0], rx), Y = __fma_rn(dj, xf.iR[3], ry), W = __fma_rn(dj, xf.iR[6], rw);
+    double iw = __builtin_amdgcn_rcp(W);
+    iw = __fma_rn(__fma_rn(-W, iw, 1.0), iw, iw);
+    const double x = X*iw, y = Y*iw;
+    const double q = __fma_rn(x, x, __fma_rn(y, y, 1.0));
+    const unsigned qhi = (unsigned)__double2hiint(q);
+    const unsigned off = (qhi >> (20 - LENS_SUB_BITS - 6)) & ((unsigned)(LENS_N - 1) << 6);
+    const double2* c = (const double2*)((const char*)tab + off);
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    const double dz = q - c0.x;
+    double Sc = __fma_rn(c3.y, dz, c3.x);
+    Sc = __fma_rn(Sc, dz, c2.y); Sc = __fma_rn(Sc, dz, c2.x); Sc = __fma_rn(Sc, dz, c1.y); Sc = __fma_rn(Sc, dz, c1.x);
+    Sc = __fma_rn(Sc, dz, c0.y);
+    const double G = Sc*iw;
+    // distance to the nearest singularity of G along x and along y, in pixels: |P| / |step| (q = 0) and _w / |step of _w| (_w = 0)
+    const double ax2 = xf.iR[0]*xf.iR[0] + xf.iR[3]*xf.iR[3] + xf.iR[6]*xf.iR[6], ay2 = xf.iR[1]*xf.iR[1] + xf.iR[4]*xf.iR[4] + xf.iR[7]*xf.iR[7];
+    const double G2 = (RP_GUARD*RP_HALF)*(RP_GUARD*RP_HALF), W2 = W*W;
+    const bool ok = lens_ok(W, qhi, hi_limit) && W2*q >= G2*fmax(ax2, ay2) && W2 >= G2*fmax(xf.iR[6]*xf.iR[6], xf.iR[7]*xf.iR[7]);
+    const int all_ok = __all(ok ? 1 : 0);
+    if (a == 0 && m == 0) *okflag = all_ok;
+    // Box: the corner nodes and the end nodes of the two middle node rows (8 samples; LDS atomics from many lanes to one
+    // address are serialised and cost more than the tile itself).  The margin of rl_box covers the bulge between them.
+    if (BOX && all_ok && (a == 0 || a == RP_N - 1) && (m == 0 || m == RP_N/2 - 1 || m == RP_N/2 || m == RP_N - 1)) {
+        const int su = __double2loint(__fma_rn(X*G, xf.f[0]*32.0, xf.c[0]*32.0) + ROUND_MAGIC) >> INTER_BITS;
+        const int sv = __double2loint(__fma_rn(Y*G, xf.f[1]*32.0, xf.c[1]*32.0) + ROUND_MAGIC) >> INTER_BITS;
+        atomicMin(&boxslot[0], su); atomicMax(&boxslot[1], su); atomicMin(&boxslot[2], sv); atomicMax(&boxslot[3], sv);
+    }
+    // node values -> coefficient a of node row m, through the scratch (LDS operations of one wave execute in program order;
+    // the empty asm statements keep the compiler from moving the reads above the writes and back)
+    U[m][a] = G;
+    asm volatile("" ::: "memory");
+    const double2* u = (const double2*)U[m];
+    const double2* mm = (const double2*)K.M[a];
+    const double2 u0 = u[0], u1 = u[1], u2 = u[2], u3 = u[3], m0 = mm[0], m1 = mm[1], m2 = mm[2], m3 = mm[3];
+    asm volatile("" ::: "memory");
+    double cf = m0.x*u0.x;
+    cf = __fma_rn(m0.y, u0.y, cf); cf = __fma_rn(m1.x, u1.x, cf); cf = __fma_rn(m1.y, u1.y, cf);
+    cf = __fma_rn(m2.x, u2.x, cf); cf = __fma_rn(m2.y, u2.y, cf); cf = __fma_rn(m3.x, u3.x, cf); cf = __fma_rn(m3.y, u3.y, cf);
+    C2[m][a] = cf;
+}
+
+// Coefficient a of tile rows r0, r0 + rstride, ... (nr of them) from the node rows' coefficients: C[r][a] = sum_m Ly[r][m] C2[m][a].
+__device__ __forceinline__ void rp_rows(const double (*C2)[RP_N], const RpConst& K, int a, int r0, int rstride, int nr, double (*C)[RP_N])
+{
+    double c2[RP_N];
+#pragma unroll
+    for (int m = 0; m < RP_N; m++) c2[m] = C2[m][a];
+#pragma unroll 2
+    for (int j = 0; j < nr; j++) {
+        const int r = r0 + j*rstride;
+        const double2* w = (const double2*)K.Ly[r];
+        const double2 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+        double cf = w0.x*c2[0];
+        cf = __fma_rn(w0.y, c2[1], cf); cf = __fma_rn(w1.x, c2[2], cf); cf = __fma_rn(w1.y, c2[3], cf);
+        cf = __fma_rn(w2.x, c2[4], cf); cf = __fma_rn(w2.y, c2[5], cf); cf = __fma_rn(w3.x, c2[6], cf); cf = __fma_rn(w3.y, c2[7], cf);
+        C[r][a] = cf;
     }
 }
 
@@ -1092,7 +1046,7 @@ __device__ __forceinline__ RlBox rl_box(const int* slot, int sw, int sh)
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 
-// Every wave: copy its share of the box rows (four per instruction: lane l fetches 16 bytes at column chunk l % 16 of row
+// One wave (the producer): copy the box rows (four per instruction: lane l fetches 16 bytes at column chunk l % 16 of row
 // 4 i + l / 16) from the frame into the LDS buffer, asynchronously (global_load_lds_dwordx4: the destination is M0 +
 // 16 * lane).  A chunk that would start at or past `limit` -- the last 16-byte chunk of the frame -- is read from there
 // instead: its bytes are never used.
@@ -1100,14 +1054,14 @@ typedef __attribute__((address_space(3))) void* lds_void_ptr;
 // the box array may depend on the copy in flight and waits for it -- and for every store issued since -- before each group
 // of tap reads, which serialises the whole kernel.  Hidden from its bookkeeping, the copy is waited for once, by rl_wait()
 // before the barrier that precedes the first read of that buffer.  M0 is saved and restored inside the statement.
-__device__ __forceinline__ void rl_issue(const RlBox& B, const uint8_t* __restrict__ frame, unsigned sstep, unsigned limit, uint4* buf, int wave, int lane)
+__device__ __forceinline__ void rl_issue(const RlBox& B, const uint8_t* __restrict__ frame, unsigned sstep, unsigned limit, uint4* buf, int lane)
 {
     if (!B.on) return;
     const unsigned lr = (unsigned)lane >> 4, lc = (unsigned)lane & 15u;
     const int ngroups = (B.nrows + 3) >> 2;
     const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr)buf;
 #pragma unroll 1
-    for (int i = wave; i < ngroups; i += BLOCK/64) {
+    for (int i = 0; i < ngroups; i++) {
         const unsigned row = (unsigned)B.by0 + min(4u*(unsigned)i + lr, (unsigned)B.nrows - 1u);
         const unsigned off = min(row*sstep + B.bxB + lc*16u, limit);
         const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)i*1024u));
@@ -1134,101 +1088,197 @@ __device__ __forceinline__ void interp_u8_raw(const uint32_t* box, unsigned ru, 
     bilin_u8_rows<HI16>(ta, tb, ru, rv, out);
 }
 
-// K1 with RP coordinates and (LDSBOX, u8 only) LDS-staged source taps.  Persistent; work items are (frame, 64 x 64 tile);
-// thread (lx, ly) = (tid % 16, tid / 16) produces columns 4 lx .. 4 lx + 3 of tile rows ly, ly + 16, ly + 32, ly + 48.
-// Per work item k:   prepare(k+1) | barrier B | issue the box of k+1 | compute k | barrier A
-//   prepare(k+1): coefficients -> C[(k+1)&1], extent of the source positions -> box slot (k+1)&3      (rp_prepare)
-//   barrier B:    every wave first waits for its own LDS-DMA of tile k (issued one work item earlier)
-//   issue:        every wave starts the LDS-DMA of its share of tile k+1's source box into buffer (k+1)&1    (rl_issue)
-//   compute k:    coordinates from C[k&1]; taps from box buffer k&1 when all four pixels of a thread lie inside the box,
-//                 otherwise straight from the frame (the box is an estimate, results never depend on it)
-//   barrier A:    nobody still reads C[k&1] / buffer k&1 when the next prepare / the issue after it overwrite them
-template <int DEPTH, int BORDER, bool LDSBOX>
+// K1 with RP coordinates, taps gathered from the frame.  Persistent; work items are (frame, 64 x 64 tile); thread (lx, ly) =
+// (tid % 16, tid / 16) produces columns 4 lx .. 4 lx + 3 of tile rows ly, ly + 16, ly + 32, ly + 48.  Software pipeline with
+// one barrier per work item k: one wave (in turn) runs rp_nodes for item k + 2, all threads run rp_rows for item k + 1
+// (thread t: coefficient t % 8 of rows t / 8 and 32 + t / 8), then the pixels of item k.
+template <int DEPTH, int BORDER>
 __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
                                                                 const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work)
 {
-    static_assert(!LDSBOX || DEPTH == GF_DEPTH_U8, "the LDS box holds u8 pixels");
-    // LDSBOX: the lens table stays in global memory (two lookups per thread and tile, L1/L2 hits) so that three workgroups
-    // fit a CU's LDS; otherwise it is copied to LDS as in the other kernels
-    __shared__ double2 s_tab_lds[(LDSBOX && GF_RL_TAB_GLOBAL) ? 1 : LENS_DOUBLES/2];
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
     __shared__ RpShared S;
-    __shared__ uint4 s_box[LDSBOX ? 2 : 1][LDSBOX ? RL_ROWS*RL_PITCH/16 : 1];
-    const double2* s_tab = (LDSBOX && GF_RL_TAB_GLOBAL) ? (const double2*)lens : s_tab_lds;
-    if (!(LDSBOX && GF_RL_TAB_GLOBAL)) load_lens_table(lens, s_tab_lds);
+    load_lens_table(lens, s_tab);
     constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
-    const RpLane L = rp_lane_consts(rp_tab, (int)threadIdx.x, S);
-    const int lx = threadIdx.x & (RT_TPR - 1), ly = threadIdx.x / RT_TPR;
-    const int lane = (int)(threadIdx.x & 63), wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const unsigned limit = ((unsigned)(A.sh - 1)*A.sstep + (unsigned)A.sw*3u - 16u) & ~15u;      // LDSBOX: frames hold >= 16 bytes (host-checked)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    rp_load_consts(rp_tab, S.K, tid, BLOCK);
+    const int lx = tid & (RT_TPR - 1), ly = tid / RT_TPR;
+    const double offx = rp_node_off(rp_tab, lane & 7), offy = rp_node_off(rp_tab, lane >> 3);
+    double z[PXT];
+#pragma unroll
+    for (int e = 0; e < PXT; e++) z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);      // exact
+    const unsigned n_it = (n_work - blockIdx.x + gridDim.x - 1)/gridDim.x;       // work items of this workgroup (>= 1)
+    auto decode = [&](unsigned k, unsigned& frame, int& tx, int& ty) -> bool {   // uniform
+        if (k >= n_it) return false;
+        const unsigned v = blockIdx.x + k*gridDim.x;
+        frame = v / tiles_pad;
+        return tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty);
+    };
+    auto nodes = [&](unsigned k) {               // one wave
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty)) rp_nodes<false>(xfs[frame], lk, s_tab, offx, offy, lane & 7, lane >> 3, tx, ty, S.U, S.K, S.C2[k & 1], &S.ok[k & 3], nullptr);
+    };
+    auto rows = [&](unsigned k) {                // all threads
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty)) rp_rows(S.C2[k & 1], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[k & 1]);
+    };
     __syncthreads();
-    {
-        const unsigned frame = blockIdx.x / tiles_pad;
-        int tx, ty;
-        const bool valid = tile_of_padded_id(blockIdx.x - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty);
-        if (valid) rp_prepare<LDSBOX>(xfs[frame], lk, s_tab, L, tx, ty, S, 0, 0, A.dh);
-        __syncthreads();
-        if (LDSBOX && valid) rl_issue(rl_box(S.box[0], A.sw, A.sh), A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[0], wave, lane);
-    }
-    unsigned it = 0;
+    if (wave == 0) { nodes(0); asm volatile("" ::: "memory"); nodes(1); }      // one wave: rp_nodes' scratch is shared
+    __syncthreads();
+    rows(0);
+    lds_barrier();
 #pragma unroll 1
-    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x, it++) {
-        const unsigned vn = v + gridDim.x;
-        const int nb = (int)((it + 1) & 1);
-        bool nvalid = false;
-        unsigned fn = 0;
-        if (vn < n_work) {
-            fn = vn / tiles_pad;
-            int txn, tyn;
-            nvalid = tile_of_padded_id(vn - fn*tiles_pad, A.tiles_x, A.tiles_y, txn, tyn);
-            if (nvalid) rp_prepare<LDSBOX>(xfs[fn], lk, s_tab, L, txn, tyn, S, nb, (int)((it + 1) & 3), A.dh);
-        }
-        if (LDSBOX && threadIdx.x < 4) S.box[(it + 2) & 3][threadIdx.x] = (threadIdx.x & 1) ? INT_MIN : INT_MAX;
-        if (LDSBOX) rl_wait();               // this wave's share of tile k's box has landed
-        lds_barrier();                       // barrier B
-        if (LDSBOX && nvalid) rl_issue(rl_box(S.box[(it + 1) & 3], A.sw, A.sh), A.src + (size_t)fn*A.sframe, A.sstep, limit, s_box[LDSBOX ? nb : 0], wave, lane);
-        const unsigned frame = v / tiles_pad;
-        int tx, ty;
-        const int buf = (int)(it & 1);
-        if (tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) {      // uniform
+    for (unsigned k = 0; k < n_it; k++) {
+        if (wave == (int)(k & 3)) nodes(k + 2);
+        rows(k + 1);
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty)) {
             const int x0 = tx*RT + lx*PXT;
-            const Xf xf = xfs[frame];        // by value: the pass loop must not go back to memory for it
+            const Xf& xf = xfs[frame];
             const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
-            RlBox B; B.on = false; B.bx0 = B.by0 = 0; B.NXq = B.NYq = 0; B.xoffB = 0;
-            if (LDSBOX) B = rl_box(S.box[it & 3], A.sw, A.sh);
-            const int X0q = B.on ? B.bx0 << INTER_BITS : 0, Y0q = B.on ? B.by0 << INTER_BITS : 0;
-            const double mu = ROUND_MAGIC - (double)X0q, mv = ROUND_MAGIC - (double)Y0q;
-            const uint32_t* box = (const uint32_t*)s_box[LDSBOX ? buf : 0];
+            const bool ok = S.ok[k & 3] != 0;
+            const int cb = (int)(k & 1);
             if (x0 < A.dw) {
-                RowC rc = row_consts(xf, ty*RT + ly);       // fills the row-independent members
-#pragma unroll GF_RL_UNROLL
+#pragma unroll 1
                 for (int pass = 0; pass < RT_NPASS; pass++) {
                     const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
                     if (y >= A.dh) break;
-                    {
-                        const double di = (double)y;
-                        rc.rx = __dadd_rn(__dmul_rn(di, xf.iR[1]), xf.iR[2]);
-                        rc.ry = __dadd_rn(__dmul_rn(di, xf.iR[4]), xf.iR[5]);
-                        rc.rw = __dadd_rn(__dmul_rn(di, xf.iR[7]), xf.iR[8]);
-                    }
+                    const RowC rc = row_consts(xf, y);
+                    int iu[PXT], iv[PXT], px[PXT][3];
+                    if (ok) rp_coords(rc, S.C[cb][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+                    else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+                    const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
+                    uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+                    store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+                }
+            }
+        }
+        lds_barrier();
+    }
+}
+
+// K1-RL: RP coordinates + source taps staged through LDS (u8).  A workgroup is four consumer waves and one producer wave:
+//   consumers (threads 0..255): the pixels of work item k -- coordinates from C[k % 3], taps from box buffer k & 1 when all
+//       four pixels of a thread lie inside the box, otherwise straight from the frame (the box is an estimate from the
+//       tile's rim nodes; results never depend on it) -- then the barrier;
+//   producer (wave 4), during the same interval: starts the LDS-DMA of work item k + 1's source box into buffer (k + 1) & 1
+//       (rl_issue; the box extent was found one interval earlier), computes coefficients, flag and box extent of work item
+//       k + 2 (rp_nodes + rp_rows; lens table read from global memory) while the DMA is in flight, waits for the DMA
+//       (s_waitcnt vmcnt(0): the producer has no stores of its own), then the barrier.
+// One barrier per work item orders everything: C is triple-buffered (k read, k + 1 waiting, k + 2 written), the box
+// double-buffered, flags and box extents live in four slots.  The consumers never wait on memory and issue no LDS-DMA (each
+// 1 KB LDS-DMA instruction holds the issuing wave for ~100 cycles).
+constexpr int BLOCK_RL = BLOCK + 64;
+struct RlShared {
+    RpConst K;
+    double U[RP_N][RP_N];           // producer's scratch
+    double C2[RP_N][RP_N];
+    double C[3][RT][RP_N];
+    int ok[4];
+    int box[4][4];                  // [slot][min u, max u, min v, max v]
+};
+
+template <int BORDER>
+__global__ void __launch_bounds__(BLOCK_RL, (GF_RL_WGS*(BLOCK_RL/64) + 3)/4) k_undistort_rotate_rl(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                                   const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work)
+{
+    constexpr int DEPTH = GF_DEPTH_U8;
+    constexpr bool HI16 = true;
+    __shared__ RlShared S;
+    __shared__ uint4 s_box[2][RL_ROWS*RL_PITCH/16];
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    const bool producer = __builtin_amdgcn_readfirstlane(tid >> 6) == BLOCK/64;
+    rp_load_consts(rp_tab, S.K, tid, BLOCK_RL);
+    if (tid < 16) (&S.box[0][0])[tid] = (tid & 1) ? INT_MIN : INT_MAX;
+    __syncthreads();
+    const unsigned n_it = (n_work - blockIdx.x + gridDim.x - 1)/gridDim.x;       // work items of this workgroup (>= 1)
+    auto decode = [&](unsigned k, unsigned& frame, int& tx, int& ty) -> bool {   // uniform
+        if (k >= n_it) return false;
+        const unsigned v = blockIdx.x + k*gridDim.x;
+        frame = v / tiles_pad;
+        return tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty);
+    };
+
+    if (producer) {
+        const double2* tab = (const double2*)lens;
+        const int a = lane & (RP_N - 1), m = lane >> 3;
+        const double offx = rp_node_off(rp_tab, a), offy = rp_node_off(rp_tab, m);
+        const unsigned limit = ((unsigned)(A.sh - 1)*A.sstep + (unsigned)A.sw*3u - 16u) & ~15u;      // frames hold >= 32 bytes (host-checked)
+        auto prepare = [&](unsigned k) {         // coefficients, flag and box extent of work item k (if it exists)
+            unsigned frame; int tx, ty;
+            if (!decode(k, frame, tx, ty)) return;
+            int* slot = S.box[k & 3];
+            if (lane < 4) slot[lane] = (lane & 1) ? INT_MIN : INT_MAX;     // same wave as the atomics: LDS keeps program order
+            asm volatile("" ::: "memory");
+            rp_nodes<true>(xfs[frame], lk, tab, offx, offy, a, m, tx, ty, S.U, S.K, S.C2, &S.ok[k & 3], slot);
+            asm volatile("" ::: "memory");
+            rp_rows(S.C2, S.K, a, m, RP_N, RT/RP_N, S.C[k % 3]);
+            asm volatile("" ::: "memory");
+        };
+        auto issue = [&](unsigned k) {           // LDS-DMA of work item k's box
+            unsigned frame; int tx, ty;
+            if (!decode(k, frame, tx, ty)) return;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // the slot's atomics have landed
+            rl_issue(rl_box(S.box[k & 3], A.sw, A.sh), A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[k & 1], lane);
+        };
+        prepare(0);
+        issue(0);
+        prepare(1);
+        rl_wait();
+        lds_barrier();
+#pragma unroll 1
+        for (unsigned k = 0; k < n_it; k++) {
+            issue(k + 1);
+            prepare(k + 2);
+            rl_wait();
+            lds_barrier();
+        }
+        return;
+    }
+
+    // consumers
+    double z[PXT];
+    const int lx = tid & (RT_TPR - 1), ly = tid / RT_TPR;
+#pragma unroll
+    for (int e = 0; e < PXT; e++) z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);
+    lds_barrier();
+#pragma unroll 1
+    for (unsigned k = 0; k < n_it; k++) {
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty)) {
+            const int x0 = tx*RT + lx*PXT;
+            const Xf xf = xfs[frame];
+            const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+            const bool ok = S.ok[k & 3] != 0;
+            RlBox B; B.on = false; B.bx0 = B.by0 = 0; B.NXq = B.NYq = 0; B.xoffB = 0;
+            if (ok) B = rl_box(S.box[k & 3], A.sw, A.sh);
+            const int X0q = B.on ? B.bx0 << INTER_BITS : 0, Y0q = B.on ? B.by0 << INTER_BITS : 0;
+            const double mu = ROUND_MAGIC - (double)X0q, mv = ROUND_MAGIC - (double)Y0q;
+            const uint32_t* box = (const uint32_t*)s_box[k & 1];
+            const int cb = (int)(k % 3);
+            if (x0 < A.dw) {
+#pragma unroll 1
+                for (int pass = 0; pass < RT_NPASS; pass++) {
+                    const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
+                    if (y >= A.dh) break;
+                    const RowC rc = row_consts(xf, y);
                     int iu[PXT], iv[PXT], px[PXT][3];
                     unsigned keep = 0;
                     bool done = false;
-                    if (S.ok[buf][rr]) {
-                        rp_coords(rc, S.C[buf][rr], L.z, x0, mu, mv, iu, iv);
-                        if (LDSBOX) {
-                            const unsigned rumax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
-                            const unsigned rvmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
-                            if (rumax < B.NXq && rvmax < B.NYq) {
+                    if (ok) {
+                        rp_coords(rc, S.C[cb][rr], z, x0, mu, mv, iu, iv);
+                        const unsigned rumax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
+                        const unsigned rvmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
+                        if (rumax < B.NXq && rvmax < B.NYq) {
 #pragma unroll
-                                for (int e = 0; e < PXT; e++) interp_u8_raw<HI16>(box, (unsigned)iu[e], (unsigned)iv[e], B.xoffB, px[e]);
-                                done = true;
-                            } else {
+                            for (int e = 0; e < PXT; e++) interp_u8_raw<HI16>(box, (unsigned)iu[e], (unsigned)iv[e], B.xoffB, px[e]);
+                            done = true;
+                        } else {
 #pragma unroll
-                                for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
-                            }
+                            for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
                         }
                     } else {
-                        coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+                        coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), (const double2*)lens, x0, iu, iv);
                     }
                     if (!done) keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
                     uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
@@ -1236,7 +1286,7 @@ __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(Rema
                 }
             }
         }
-        lds_barrier();                       // barrier A
+        lds_barrier();
     }
 }
 
@@ -1247,21 +1297,28 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, cons
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     __shared__ RpShared S;
     load_lens_table(lens, s_tab);
-    const RpLane L = rp_lane_consts(rp_tab, (int)threadIdx.x, S);
-    const int lx = threadIdx.x & (RT_TPR - 1), ly = threadIdx.x / RT_TPR;
+    const int tid = (int)threadIdx.x, lane = tid & 63;
+    rp_load_consts(rp_tab, S.K, tid, BLOCK);
+    const int lx = tid & (RT_TPR - 1), ly = tid / RT_TPR;
     const int tx = blockIdx.x, ty = blockIdx.y;
     __syncthreads();
-    rp_prepare<false>(xf, lk, s_tab, L, tx, ty, S, 0, 0, h);
+    if (tid < 64) rp_nodes<false>(xf, lk, s_tab, rp_node_off(rp_tab, lane & 7), rp_node_off(rp_tab, lane >> 3), lane & 7, lane >> 3, tx, ty, S.U, S.K, S.C2[0], &S.ok[0], nullptr);
+    __syncthreads();
+    rp_rows(S.C2[0], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[0]);
     __syncthreads();
     const int x0 = tx*RT + lx*PXT;
     if (x0 >= w) return;
+    const bool ok = S.ok[0] != 0;
+    double z[PXT];
+#pragma unroll
+    for (int e = 0; e < PXT; e++) z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);
 #pragma unroll 1
     for (int pass = 0; pass < RT_NPASS; pass++) {
         const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
         if (y >= h) break;
         const RowC rc = row_consts(xf, y);
         int iu[PXT], iv[PXT];
-        if (S.ok[0][rr]) rp_coords(rc, S.C[0][rr], L.z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+        if (ok) rp_coords(rc, S.C[0][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
         else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
         int16_t* m1 = (int16_t*)(map1 + (size_t)y*m1step);
         uint16_t* m2 = (uint16_t*)(map2 + (size_t)y*m2step);
@@ -1271,130 +1328,6 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, cons
                 *(uint32_t*)(m1 + 2*(x0 + e)) = (uint32_t)(uint16_t)(iu[e] >> INTER_BITS) | ((uint32_t)(uint16_t)(iv[e] >> INTER_BITS) << 16);   // (short) cast wraps (Q1)
                 m2[x0 + e] = (uint16_t)((iv[e] & 31)*32 + (iu[e] & 31));
             }
-    }
-}
-
-// K1-LDS: the same work with the source taps staged through LDS.  The vector-memory path returns ~11 bytes per clock
-// and CU to gathers that miss L1 (measured: 47 TD-busy cycles per 64-lane 8-byte load), and the direct kernel asks it for
-// 16 bytes per output pixel; that, not HBM, bounds it.  Here every workgroup, per 64 x 32 output tile,
-//   1. estimates the tile's source box from 8 boundary samples (corners + edge midpoints, +-1 px margin, clamped),
-//   2. copies the box into LDS with aligned 16-byte loads (each source byte requested once), repacking 3-byte pixels
-//      to one dword each on the way,
-//   3. gathers the taps from LDS (aligned ds_read2_b32).
-// A pixel whose taps fall outside the box (the estimate is not a bound) takes the direct path, so results never depend
-// on the estimate.  Needs a 16-byte aligned frame base, row pitch and frame stride (host-checked); a box that does not
-// fit LDS_SRC_BYTES (strong zoom-out or rotation) sends the whole tile down the direct path.
-// Persistent like K1: the lens table is loaded once per workgroup; three barriers per tile.
-constexpr int LT_W = 64;
-constexpr int LT_TPR = LT_W/PXT;                 // 16 threads per output row
-constexpr int LT_RPP = BLOCK/LT_TPR;             // 16 rows per pass
-constexpr int LDS_SRC_BYTES = 24576;             // 16 KB lens table + 24 KB source box = 3 workgroups per CU
-
-template <int DEPTH, int BORDER, int NPASS>
-__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_lds(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
-                                                                 unsigned tiles_pad, unsigned n_work)
-{
-    __shared__ double2 s_tab[LENS_DOUBLES/2];
-    __shared__ uint4 s_src[LDS_SRC_BYTES/16];
-    __shared__ int s_box[4];                         // min sx, max sx, min sy, max sy of the boundary samples
-    constexpr int PB = DEPTH == GF_DEPTH_U8 ? 3 : 6;           // source bytes per pixel
-    constexpr int LPB = DEPTH == GF_DEPTH_U8 ? 4 : 8;          // LDS bytes per pixel
-    constexpr int LT_H = LT_RPP*NPASS;
-    constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
-    const int tid = threadIdx.x;
-    load_lens_table(lens, s_tab);                    // ends with __syncthreads()
-    const int lx = tid & (LT_TPR - 1), ly = tid / LT_TPR;
-
-#pragma unroll 1
-    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
-        const unsigned frame = v / tiles_pad;
-        int tx, ty;
-        if (!tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) continue;     // uniform
-        const int x0 = tx*LT_W + lx*PXT;
-        const Xf& xf = xfs[frame];
-        const unsigned hi_limit = lens_hi_limit(xf, lk);
-        const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
-
-        __syncthreads();                             // the previous tile's LDS taps and s_box are no longer read
-        if (tid < 4) s_box[tid] = (tid & 1) ? INT_MIN : INT_MAX;
-        if (tid < 8) {                               // boundary samples: k = 0..7 around the tile's rim (same wave as the reset)
-            const int xa = tx*LT_W, xb = min(xa + LT_W - 1, A.dw - 1), ya = ty*LT_H, yb = min(ya + LT_H - 1, A.dh - 1);
-            const int k = tid < 4 ? tid : tid + 1;   // skip the centre of the 3x3 grid
-            const int kx = k % 3, ky = k / 3;
-            const int px_ = kx == 0 ? xa : kx == 1 ? (xa + xb) >> 1 : xb, py_ = ky == 0 ? ya : ky == 1 ? (ya + yb) >> 1 : yb;
-            int su, sv;
-            coord_q5(row_consts(xf, py_), xf, lk, hi_limit, s_tab, px_, su, sv);
-            su >>= INTER_BITS; sv >>= INTER_BITS;
-            atomicMin(&s_box[0], su); atomicMax(&s_box[1], su); atomicMin(&s_box[2], sv); atomicMax(&s_box[3], sv);
-        }
-
-        int iu[NPASS][PXT], iv[NPASS][PXT];
-#pragma unroll
-        for (int p = 0; p < NPASS; p++) {
-            const int y = ty*LT_H + p*LT_RPP + ly;
-            if (x0 < A.dw && y < A.dh) {
-                coord_q5x4(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, iu[p], iv[p]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < PXT; i++) iu[p][i] = iv[p][i] = 0;
-            }
-        }
-        __syncthreads();
-
-        LdsBox L{(lds_u32)s_src, 0, 0, 0, 0, 0, 0, false};
-        {
-            // tap positions: samples +-1 px, clamped to the positions whose four taps are inside the frame.  The four
-            // values are the same in every lane: keep them in scalar registers.
-            const int smin_x = __builtin_amdgcn_readfirstlane(s_box[0]), smax_x = __builtin_amdgcn_readfirstlane(s_box[1]);
-            const int smin_y = __builtin_amdgcn_readfirstlane(s_box[2]), smax_y = __builtin_amdgcn_readfirstlane(s_box[3]);
-            const int bx0 = max(smin_x, 1) - 1, bx1 = min(smax_x, s.w - 3) + 1;       // max(a - 1, 0), min(a + 1, w - 2) without overflow
-            const int by0 = max(smin_y, 1) - 1, by1 = min(smax_y, s.h - 3) + 1;
-            if (bx0 <= bx1 && by0 <= by1) {
-                const int bx0a = bx0 & ~15;                              // 16-pixel units: 48 (u8) / 96 (u16) source bytes
-                const unsigned units = (unsigned)(bx1 + 2 - bx0a + 15) >> 4, rows = (unsigned)(by1 - by0 + 2), pitch = units*16u;
-                if ((unsigned long long)rows*pitch*LPB <= (unsigned)LDS_SRC_BYTES) {
-                    const size_t valid = (size_t)(s.h - 1)*s.step + (size_t)s.w*PB;      // bytes of the frame
-                    for (unsigned r = (unsigned)tid >> 3; r < rows; r += BLOCK/8)
-                        for (unsigned k = (unsigned)tid & 7u; k < units; k += 8) {
-                            const size_t goff = (size_t)(by0 + (int)r)*s.step + (size_t)(bx0a + 16*(int)k)*PB;
-                            uint32_t d[PB*4];
-#pragma unroll
-                            for (int c = 0; c < PB; c++) {
-                                // aligned 16-byte chunk: if it starts inside the frame it lies in the frame's pages
-                                uint4 q = make_uint4(0, 0, 0, 0);
-                                if (goff + 16*c < valid) q = *(const uint4*)(s.base + goff + 16*c);
-                                d[4*c] = q.x; d[4*c+1] = q.y; d[4*c+2] = q.z; d[4*c+3] = q.w;
-                            }
-                            uint4* dst = s_src + ((r*pitch + 16u*k)*LPB >> 4);
-                            if (DEPTH == GF_DEPTH_U8) {
-#pragma unroll
-                                for (int m = 0; m < 4; m++)     // 4 pixels = 3 dwords -> 4 dwords (byte 3 of each is don't-care)
-                                    dst[m] = make_uint4(d[3*m], __builtin_amdgcn_alignbyte(d[3*m+1], d[3*m], 3),
-                                                        __builtin_amdgcn_alignbyte(d[3*m+2], d[3*m+1], 2), d[3*m+2] >> 8);
-                            } else {
-#pragma unroll
-                                for (int m = 0; m < 8; m++)     // 2 pixels = 3 dwords -> 4 dwords
-                                    dst[m] = make_uint4(d[3*m], d[3*m+1], __builtin_amdgcn_alignbit(d[3*m+2], d[3*m+1], 16), d[3*m+2] >> 16);
-                            }
-                        }
-                    L.X0 = (unsigned)bx0 << INTER_BITS; L.Y0 = (unsigned)by0 << INTER_BITS;
-                    L.NX = (unsigned)(bx1 - bx0 + 1) << INTER_BITS; L.NY = (unsigned)(by1 - by0 + 1) << INTER_BITS;
-                    L.pitch = pitch; L.xoff = (unsigned)(bx0 - bx0a); L.on = true;
-                }
-            }
-        }
-        __syncthreads();
-
-#pragma unroll
-        for (int p = 0; p < NPASS; p++) {
-            const int y = ty*LT_H + p*LT_RPP + ly;
-            if (x0 < A.dw && y < A.dh) {
-                int px[PXT][3];
-                const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu[p], iv[p], A.cval, px, L);
-                uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
-                store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
-            }
-        }
     }
 }
 
@@ -2296,33 +2229,12 @@ static int fused_checks(const char* fn, void* ctx, int depth, const void* src, i
     return GF_OK;
 }
 
-static int launch_fused(Ctx* c, bool lds_tiles, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+static int launch_fused(Ctx* c, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                         void* dst, int dw, int dh, size_t dstep, size_t dframe, const double* lens, LensK lk,
                         const gf_frame_xform* xf_dev, int n_frames, int border, const double* bv, hipStream_t stream)
 {
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
-    if (lds_tiles) {               // LDS-staged source taps
-        const int npass = depth == GF_DEPTH_U8 ? 2 : 1;
-        A.tiles_x = (dw + LT_W - 1)/LT_W; A.tiles_y = (dh + LT_RPP*npass - 1)/(LT_RPP*npass);
-        const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
-        const unsigned long long n_work = (unsigned long long)tiles_pad*(unsigned)n_frames;
-        if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many tiles in one call (%lld)", "gf_undistort_rotate_c3", (long long)n_work);
-        unsigned blocks = (unsigned)c->n_cu*WG_PER_CU_LDS & ~(unsigned)(NXCD - 1);
-        if (blocks == 0) blocks = NXCD;
-        if (blocks > n_work) blocks = (unsigned)n_work;
-        dim3 grid(blocks, 1);
-#define LAUNCH_LDS(DEPTH_, BORDER_, NP_) hipLaunchKernelGGL((k_undistort_rotate_lds<DEPTH_, BORDER_, NP_>), grid, dim3(BLOCK), 0, stream, A, (const Xf*)xf_dev, lens, lk, tiles_pad, (unsigned)n_work)
-        if (depth == GF_DEPTH_U8) {
-            if (border == GF_BORDER_CONSTANT) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_CONSTANT, 2);
-            else if (border == GF_BORDER_REPLICATE) LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_REPLICATE, 2);
-            else LAUNCH_LDS(GF_DEPTH_U8, GF_BORDER_TRANSPARENT, 2);
-        } else {
-            if (border == GF_BORDER_CONSTANT) LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_CONSTANT, 1);
-            else if (border == GF_BORDER_REPLICATE) LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_REPLICATE, 1);
-            else LAUNCH_LDS(GF_DEPTH_U16, GF_BORDER_TRANSPARENT, 1);
-        }
-#undef LAUNCH_LDS
-    } else if (c->k1_mode != GF_KERNEL_DIRECT) {
+    if (c->k1_mode != GF_KERNEL_DIRECT) {
         // RP coordinates on 64 x 64 tiles; u8 frames with 16-byte aligned base, row pitch and frame stride also stage their
         // source taps through LDS (mode 2, the default)
         A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
@@ -2335,21 +2247,14 @@ static int launch_fused(Ctx* c, bool lds_tiles, int depth, const void* src, int 
         if (blocks == 0) blocks = NXCD;
         if (blocks > n_work) blocks = (unsigned)n_work;
         dim3 grid(blocks, 1);
-#define LAUNCH_RP(DEPTH_, BORDER_, BOX_) hipLaunchKernelGGL((k_undistort_rotate_rp<DEPTH_, BORDER_, BOX_>), grid, dim3(BLOCK), 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work)
-        if (depth == GF_DEPTH_U8 && ldsbox) {
-            if (border == GF_BORDER_CONSTANT) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_CONSTANT, true);
-            else if (border == GF_BORDER_REPLICATE) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_REPLICATE, true);
-            else LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_TRANSPARENT, true);
-        } else if (depth == GF_DEPTH_U8) {
-            if (border == GF_BORDER_CONSTANT) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_CONSTANT, false);
-            else if (border == GF_BORDER_REPLICATE) LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_REPLICATE, false);
-            else LAUNCH_RP(GF_DEPTH_U8, GF_BORDER_TRANSPARENT, false);
+        if (ldsbox) {
+            dim3 block(BLOCK_RL);
+            if (border == GF_BORDER_CONSTANT)       hipLaunchKernelGGL((k_undistort_rotate_rl<GF_BORDER_CONSTANT>), grid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
+            else if (border == GF_BORDER_REPLICATE) hipLaunchKernelGGL((k_undistort_rotate_rl<GF_BORDER_REPLICATE>), grid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
+            else                                    hipLaunchKernelGGL((k_undistort_rotate_rl<GF_BORDER_TRANSPARENT>), grid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
         } else {
-            if (border == GF_BORDER_CONSTANT) LAUNCH_RP(GF_DEPTH_U16, GF_BORDER_CONSTANT, false);
-            else if (border == GF_BORDER_REPLICATE) LAUNCH_RP(GF_DEPTH_U16, GF_BORDER_REPLICATE, false);
-            else LAUNCH_RP(GF_DEPTH_U16, GF_BORDER_TRANSPARENT, false);
+            DISPATCH_DEPTH_BORDER(k_undistort_rotate_rp, depth, border, grid, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
         }
-#undef LAUNCH_RP
     } else {
         // persistent grid: WG_PER_CU workgroups per CU (what the kernel's register and LDS use allows), a multiple of 8
         const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
@@ -2376,8 +2281,7 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     DeviceGuard dg(c->device);
     const double* lens; LensK lk;
     rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
-    const bool aligned16 = ((uintptr_t)src & 15) == 0 && (sstep & 15) == 0 && (sframe & 15) == 0;
-    return launch_fused(c, aligned16 && g_use_lds_tiles, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
+    return launch_fused(c, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
                         border, bv, (hipStream_t)stream);
 }
 

@@ -9,10 +9,8 @@ for v in "$@"; do
   case $v in
     nomath)   hipcc $F -DGF_ABL_NOMATH   -o tools/_build/lib_nomath.so   gyroflow_amd/csrc/gfremap.hip ;;
     nogather) hipcc $F -DGF_ABL_NOGATHER -o tools/_build/lib_nogather.so gyroflow_amd/csrc/gfremap.hip ;;
-    ldsaligned) hipcc $F -DGF_ABL_LDS_ALIGNED -o tools/_build/lib_ldsaligned.so gyroflow_amd/csrc/gfremap.hip ;;
-    noatomic) hipcc $F -DGF_ABL_NO_ATOMIC -o tools/_build/lib_noatomic.so gyroflow_amd/csrc/gfremap.hip ;;
-    x2) hipcc $F -DGF_EXP_X2 -o tools/_build/lib_x2.so gyroflow_amd/csrc/gfremap.hip ;;
     noload) hipcc $F -DGF_ABL_NOLOAD -o tools/_build/lib_noload.so gyroflow_amd/csrc/gfremap.hip ;;
+    nostore) hipcc $F -DGF_ABL_NOSTORE -o tools/_build/lib_nostore.so gyroflow_amd/csrc/gfremap.hip ;;
     k1_*) # k1_<pipeline>_<waves>, e.g. k1_0_8
         IFS=_ read -r _ pl wv <<< "$v"
         hipcc $F -DGF_K1_PIPELINE=$pl -DGF_K1_WAVES=$wv -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
