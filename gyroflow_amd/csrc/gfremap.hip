@@ -568,9 +568,9 @@ __device__ __forceinline__ void bilin_u8_rows(uint64_t ta, uint64_t tb, unsigned
     out[0] = (int)(HI16 ? rB : rB >> 16); out[1] = (int)(HI16 ? rG : rG >> 16); out[2] = (int)(HI16 ? rR : rR >> 16);
 }
 
-// (iu, iv): non-negative Q5 coordinates with sx = iu >> 5 in [0, w-3], sy = iv >> 5 in [0, h-2].
-// The caller routes the frame's last source column pair to the general path, so the two spare bytes of each 8-byte
-// load never lie past the end of the frame.  32-bit offsets from the uniform frame base (frames are < 2 GiB).
+// (iu, iv): non-negative Q5 coordinates with sx = iu >> 5 in [0, w-4], sy = iv >> 5 in [0, h-2].
+// The caller routes the frame's last three source columns to the general path, so the spare bytes of each 12-byte
+// load never lie past the end of the row.  32-bit offsets from the uniform frame base (frames are < 2 GiB).
 struct TapsU8 { uint64_t a, b; };          // the 8 bytes at (sx, sy) and at (sx, sy+1)
 
 __device__ __forceinline__ TapsU8 fetch_u8_interior(const uint8_t* __restrict__ base, unsigned step, unsigned iu, unsigned iv)
@@ -584,8 +584,20 @@ __device__ __forceinline__ TapsU8 fetch_u8_interior(const uint8_t* __restrict__ 
     const uint64_t ta = (uint64_t)off*0x9E3779B97F4A7C15ull;
     return TapsU8{ta, ta ^ (uint64_t)step};
 #else
+#ifndef GF_EXP_UNALIGNED_TAPS
+    // Aligned 12-byte loads + v_alignbyte_b32: the vector memory path splits a load that is not dword aligned, which made the
+    // former unaligned 8-byte loads the kernel's bottleneck (26.3 -> 22.5 us per 4K frame on MI355X).  The 12 bytes from the
+    // aligned address cover the 6 tap bytes at any byte phase; the caller keeps sx <= w - 4 so that they stay inside the row.
+    struct alignas(4) D3 { uint32_t a, b, c; };
+    const unsigned o0 = off & ~3u, o1 = (off + step) & ~3u;
+    const D3 r0 = *(const D3*)(base + o0), r1 = *(const D3*)(base + o1);
+    const uint64_t ta = (uint64_t)__builtin_amdgcn_alignbyte(r0.b, r0.a, off) | ((uint64_t)__builtin_amdgcn_alignbyte(r0.c, r0.b, off) << 32);
+    const uint64_t tb = (uint64_t)__builtin_amdgcn_alignbyte(r1.b, r1.a, off + step) | ((uint64_t)__builtin_amdgcn_alignbyte(r1.c, r1.b, off + step) << 32);
+    return TapsU8{ta, tb};
+#else
     typedef uint64_t __attribute__((aligned(1))) u64_unaligned;
     return TapsU8{*(const u64_unaligned*)(base + off), *(const u64_unaligned*)(base + (off + step))};
+#endif
 #endif
 }
 
@@ -631,8 +643,18 @@ __device__ __forceinline__ TapsU16 fetch_u16_interior(const uint8_t* __restrict_
     const unsigned off = __umul24(iv >> 5, step) + __umul24(iu >> 5, 6u);
 #endif
     TapsU16 t;
+#ifndef GF_EXP_UNALIGNED_TAPS
+    // aligned 16-byte loads (see fetch_u8_interior); off is even, so the 12 tap bytes start at byte 0 or 2 of the first dword.
+    // The caller keeps sx <= w - 3 so that the 16 bytes stay inside the row.
+    struct alignas(4) D4 { uint32_t a, b, c, d; };
+    const unsigned s1 = off + step;
+    const D4 r0 = *(const D4*)(base + (off & ~3u)), r1 = *(const D4*)(base + (s1 & ~3u));
+    t.a.a = __builtin_amdgcn_alignbyte(r0.b, r0.a, off); t.a.b = __builtin_amdgcn_alignbyte(r0.c, r0.b, off); t.a.c = __builtin_amdgcn_alignbyte(r0.d, r0.c, off);
+    t.b.a = __builtin_amdgcn_alignbyte(r1.b, r1.a, s1);  t.b.b = __builtin_amdgcn_alignbyte(r1.c, r1.b, s1);  t.b.c = __builtin_amdgcn_alignbyte(r1.d, r1.c, s1);
+#else
     __builtin_memcpy(&t.a, base + off, 12);
     __builtin_memcpy(&t.b, base + (off + step), 12);
+#endif
     return t;
 }
 
@@ -657,10 +679,10 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
     static_assert(PXT == 4, "interior test is written for 4 pixels");
     static_assert(!HI16 || DEPTH == GF_DEPTH_U8, "HI16 is a u8 representation");
     unsigned keep = 0;
-    // u8 taps are fetched with 8-byte loads (2 spare bytes): keeping the last source column pair (sx == w-2) out of the
-    // fast path means those spare bytes are always inside the row, never past the end of the frame.
+    // Taps are fetched with aligned 12-byte (u8) / 16-byte (u16) loads: keeping the last source columns out of the fast path
+    // means the spare bytes are always inside the row, never past the end of the frame.
     // Interior: 0 <= sx < w1 and 0 <= sy < h1 for all four pixels, tested on the Q5 values (negative ones are huge as unsigned).
-    const unsigned w1 = (unsigned)(s.w - 1) - ((DEPTH == GF_DEPTH_U8 && s.w > 1) ? 1u : 0u), h1 = (unsigned)(s.h - 1);
+    const unsigned w1 = (unsigned)max(s.w - (DEPTH == GF_DEPTH_U8 ? 3 : 2), 0), h1 = (unsigned)(s.h - 1);
     const unsigned umax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
     const unsigned vmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
     if (umax < (w1 << INTER_BITS) && vmax < (h1 << INTER_BITS)) {
@@ -687,7 +709,7 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
 template <int DEPTH>
 __device__ __forceinline__ bool fetch4(const SrcImg& s, const int* iu, const int* iv, typename TapsT<DEPTH>::T* T)
 {
-    const unsigned w1 = (unsigned)(s.w - 1) - ((DEPTH == GF_DEPTH_U8 && s.w > 1) ? 1u : 0u), h1 = (unsigned)(s.h - 1);
+    const unsigned w1 = (unsigned)max(s.w - (DEPTH == GF_DEPTH_U8 ? 3 : 2), 0), h1 = (unsigned)(s.h - 1);
     const unsigned umax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
     const unsigned vmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
     const bool interior = umax < (w1 << INTER_BITS) && vmax < (h1 << INTER_BITS);
