@@ -101,6 +101,7 @@ def ctx(device_index):
 
 
 KERNEL_DIRECT, KERNEL_RP, KERNEL_RL = 0, 1, 2
+KERNEL_DEFAULT = KERNEL_RP
 
 
 def set_kernel_mode(device_index, mode):

@@ -93,7 +93,7 @@ thread_local char g_err[512] = "";
 // as measured on MI355X and the default), rp = RP coordinates (per-row polynomials) with taps gathered from the frame,
 // rl = RP coordinates and, for u8 frames, source taps staged through LDS by LDS-DMA.  The kernels of a mode use the same
 // coordinate arithmetic, so fused output == maps + remap bit for bit in every mode.
-const int g_k1_mode = !getenv("GF_K1") ? GF_KERNEL_DIRECT : !strcmp(getenv("GF_K1"), "rp") ? GF_KERNEL_RP : !strcmp(getenv("GF_K1"), "rl") ? GF_KERNEL_RL : GF_KERNEL_DIRECT;
+const int g_k1_mode = !getenv("GF_K1") ? GF_KERNEL_RP : !strcmp(getenv("GF_K1"), "direct") ? GF_KERNEL_DIRECT : !strcmp(getenv("GF_K1"), "rl") ? GF_KERNEL_RL : GF_KERNEL_RP;
 const unsigned WG_PER_CU_RP = getenv("GF_WG_PER_CU_RP") ? (unsigned)atoi(getenv("GF_WG_PER_CU_RP")) : 16u;
 const unsigned WG_PER_CU_RL = getenv("GF_WG_PER_CU_RL") ? (unsigned)atoi(getenv("GF_WG_PER_CU_RL")) : 8u;
 
@@ -1431,6 +1431,76 @@ __global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8
     }
 }
 
+// K1b with RP coordinates (the same functions and tile grid as k_undistort_rotate_rp, so that the fused blend equals the
+// separate passes bit for bit in the RP / RL modes too): one 64 x 64 tile of one output frame per workgroup.  The
+// coefficients of all n_blend <= RB_MAX input frames are prepared first (four frames at a time, one wave per frame), then
+// the pixels are produced row pass by row pass with the blend loop innermost, as in k_undistort_rotate_blend.
+constexpr int RB_MAX = 8;
+template <int DEPTH, int BORDER>
+__global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                                      const double* __restrict__ rp_tab, int frames_per_group, int n_blend)
+{
+    __shared__ double2 s_tab[LENS_DOUBLES/2];
+    __shared__ RpConst K;
+    __shared__ double U[BLOCK/64][RP_N][RP_N];
+    __shared__ double C2[BLOCK/64][RP_N][RP_N];
+    __shared__ double C[RB_MAX][RT][RP_N];
+    __shared__ int okf[RB_MAX];
+    load_lens_table(lens, s_tab);
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    rp_load_consts(rp_tab, K, tid, BLOCK);
+    int tx, ty;
+    tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
+    const int g = blockIdx.y;
+    const double offx = rp_node_off(rp_tab, lane & 7), offy = rp_node_off(rp_tab, lane >> 3);
+    __syncthreads();
+#pragma unroll 1
+    for (int b0 = 0; b0 < n_blend; b0 += BLOCK/64) {
+        if (b0 + wave < n_blend)
+            rp_nodes<false>(xfs[g*frames_per_group + b0 + wave], lk, s_tab, offx, offy, lane & 7, lane >> 3, tx, ty, U[wave], K, C2[wave], &okf[b0 + wave], nullptr);
+        __syncthreads();
+        for (int j = 0; j < BLOCK/64 && b0 + j < n_blend; j++) rp_rows(C2[j], K, tid & 7, tid >> 3, RT/2, 2, C[b0 + j]);
+        __syncthreads();
+    }
+    const int lx = tid & (RT_TPR - 1), ly = tid / RT_TPR;
+    const int x0 = tx*RT + lx*PXT;
+    if (x0 >= A.dw) return;
+    double z[PXT];
+#pragma unroll
+    for (int e = 0; e < PXT; e++) z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);
+    const double wgt = 1.0/(double)n_blend;       // Python: 1/(self.hyperlapse_num_blended_frames)
+#pragma unroll 1
+    for (int pass = 0; pass < RT_NPASS; pass++) {
+        const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
+        if (y >= A.dh) break;
+        double acc[PXT][3];
+#pragma unroll
+        for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0.0;
+#pragma unroll 1
+        for (int b = 0; b < n_blend; b++) {
+            const int frame = g*frames_per_group + b;
+            const Xf& xf = xfs[frame];
+            const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+            const RowC rc = row_consts(xf, y);
+            int iu[PXT], iv[PXT], o[PXT][3];
+            if (okf[b]) rp_coords(rc, C[b][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+            else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+            remap4<DEPTH, BORDER>(s, iu, iv, A.cval, o);
+#pragma unroll
+            for (int i = 0; i < PXT; i++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[i][c]));
+        }
+        int px[PXT][3];
+#pragma unroll
+        for (int i = 0; i < PXT; i++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) px[i][c] = (int)acc[i][c];      // astype(uint): truncation
+        uint8_t* drow = A.dst + (size_t)g*A.dframe + (size_t)y*A.dstep;
+        store_px<DEPTH>(drow, x0, A.dw, px, 0u, A.dst_vec_ok);
+    }
+}
+
 // K2: materialised maps.  One thread per output pixel and pass, 64 x 64 tiles (16 KB lens table per workgroup).
 template <bool FIXED>
 __global__ void __launch_bounds__(BLOCK) k_fisheye_maps(Xf xf, LensK lk, const double* __restrict__ lens, int w, int h,
@@ -2322,6 +2392,16 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
     const double* lens; LensK lk;
     rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
+    if (c->k1_mode != GF_KERNEL_DIRECT && n_blend <= RB_MAX) {      // RP coordinates, as the fused kernel of this mode
+        A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
+        dim3 grid(A.tiles_x*A.tiles_y, n_out);
+#define LAUNCH_BRP(DEPTH_, BORDER_) hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend)
+        if (depth == GF_DEPTH_U8) { if (border == GF_BORDER_CONSTANT) LAUNCH_BRP(GF_DEPTH_U8, GF_BORDER_CONSTANT); else LAUNCH_BRP(GF_DEPTH_U8, GF_BORDER_REPLICATE); }
+        else                      { if (border == GF_BORDER_CONSTANT) LAUNCH_BRP(GF_DEPTH_U16, GF_BORDER_CONSTANT); else LAUNCH_BRP(GF_DEPTH_U16, GF_BORDER_REPLICATE); }
+#undef LAUNCH_BRP
+        HIP_TRY(hipGetLastError());
+        return GF_OK;
+    }
     dim3 grid(A.tiles_x*A.tiles_y, n_out);
     if (depth == GF_DEPTH_U8) {
         if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);

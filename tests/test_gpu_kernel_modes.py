@@ -1,5 +1,6 @@
-"""The alternative variants of the fused kernel and of the CV_16SC2 map kernel (gf_ctx_set_kernel_mode): RP = coordinates
-from per-row polynomials on 64 x 64 tiles, RL = RP + source taps staged through LDS by LDS-DMA.  Same bars as the default
+"""Every variant of the fused kernels and of the CV_16SC2 map kernel (gf_ctx_set_kernel_mode): DIRECT = per-pixel lens
+table, RP = coordinates from per-tile polynomials on 64 x 64 tiles (the default), RL = RP + source taps staged through LDS
+by LDS-DMA.  Same bars as the default
 variant: fixed-point maps identical to the oracle except < 2e-6 of entries by one Q5 step, fused output == maps + remap
 bit for bit, pixels identical to the oracle chain wherever the maps agree.  Sizes are realistic on purpose: the polynomial
 path needs an output focal length of at least 256 px (smaller frames take the per-pixel path, covered elsewhere)."""
@@ -14,12 +15,12 @@ from conftest import GOLDEN, preset_path
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["rp", "rl"])
+@pytest.fixture(params=["direct", "rp", "rl"])
 def mode(request, gpu):
     from gyroflow_amd import _lib
-    _lib.set_kernel_mode(gpu.index or 0, {"rp": _lib.KERNEL_RP, "rl": _lib.KERNEL_RL}[request.param])
+    _lib.set_kernel_mode(gpu.index or 0, {"direct": _lib.KERNEL_DIRECT, "rp": _lib.KERNEL_RP, "rl": _lib.KERNEL_RL}[request.param])
     yield request.param
-    _lib.set_kernel_mode(gpu.index or 0, _lib.KERNEL_DIRECT)
+    _lib.set_kernel_mode(gpu.index or 0, _lib.KERNEL_DEFAULT)
 
 
 def _q5(m1, m2):
@@ -94,3 +95,25 @@ def test_modes_batch_u8_u16_and_unaligned(gpu, mode):
         for i in range(3):
             m1, m2 = cal.get_maps(1.0, new_img_dim=(w, h), output_dim=(ow, oh), update_new_K=False, quat=q[i], device=gpu)
             assert torch.equal(fused[i], cv.remap(frames[i], m1, m2, cv.INTER_LINEAR, borderMode=1)), (dtype, pad, i)
+
+
+@pytest.mark.parametrize("dtype,tdtype", [(np.uint8, torch.uint8), (np.uint16, torch.uint16)])
+def test_modes_fused_blend_equals_separate_passes(gpu, mode, dtype, tdtype):
+    """Hyperlapse: the fused remap + blend kernel equals remap, float64 accumulate and truncating cast done as separate passes,
+    bit for bit, in every mode (1920x1080, 3 input frames per output frame, 2 output frames)."""
+    from gyroflow_amd import FisheyeCalibrator, synthetic_frames, cv
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    w, h, ow, oh = 1920, 1080, 1920, 1080
+    q = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))["stab_transform"][500:500 + 30 * 7:30, 3:7]
+    xf_dev = cv.xforms_to_device(cal.frame_xforms(1.0, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
+    ring = synthetic_frames(w, h, n=2, dtype=dtype, seed=31)
+    frames = torch.from_numpy(np.stack([ring[i % 2] for i in range(7)])).to(gpu)
+    fused = cv.undistort_rotate_blend(frames, cal.D, xf_dev, (ow, oh), 4, 3, borderMode=1)      # groups of 4 frames, 3 blended
+    assert fused.shape == (2, oh, ow, 3)
+    remapped = cv.undistort_rotate(frames, cal.D, xf_dev, (ow, oh), borderMode=1)
+    for g in range(2):
+        acc = torch.zeros((oh, ow, 3), dtype=torch.float64, device=gpu)
+        for b in range(3):
+            cv.blend_accumulate(remapped[4 * g + b], acc, 1 / 3, b == 0)
+        assert torch.equal(fused[g], cv.blend_finalize(acc, tdtype)), (mode, g)
