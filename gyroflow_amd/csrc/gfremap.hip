@@ -1433,10 +1433,10 @@ __global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8
 
 // K1b with RP coordinates (the same functions and tile grid as k_undistort_rotate_rp, so that the fused blend equals the
 // separate passes bit for bit in the RP / RL modes too): one 64 x 64 tile of one output frame per workgroup.  The
-// coefficients of all n_blend <= RB_MAX input frames are prepared first (four frames at a time, one wave per frame), then
+// coefficients of all n_blend <= RB (4 or RB_MAX) input frames are prepared first (four frames at a time, one wave per frame), then
 // the pixels are produced row pass by row pass with the blend loop innermost, as in k_undistort_rotate_blend.
 constexpr int RB_MAX = 8;
-template <int DEPTH, int BORDER>
+template <int DEPTH, int BORDER, int RB>
 __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
                                                                       const double* __restrict__ rp_tab, int frames_per_group, int n_blend)
 {
@@ -1444,8 +1444,8 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A
     __shared__ RpConst K;
     __shared__ double U[BLOCK/64][RP_N][RP_N];
     __shared__ double C2[BLOCK/64][RP_N][RP_N];
-    __shared__ double C[RB_MAX][RT][RP_N];
-    __shared__ int okf[RB_MAX];
+    __shared__ double C[RB][RT][RP_N];
+    __shared__ int okf[RB];
     load_lens_table(lens, s_tab);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     rp_load_consts(rp_tab, K, tid, BLOCK);
@@ -2395,7 +2395,8 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
     if (c->k1_mode != GF_KERNEL_DIRECT && n_blend <= RB_MAX) {      // RP coordinates, as the fused kernel of this mode
         A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
         dim3 grid(A.tiles_x*A.tiles_y, n_out);
-#define LAUNCH_BRP(DEPTH_, BORDER_) hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend)
+#define LAUNCH_BRP(DEPTH_, BORDER_) do { if (n_blend <= 4) hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_, 4>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend); \
+                                          else hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_, RB_MAX>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend); } while (0)
         if (depth == GF_DEPTH_U8) { if (border == GF_BORDER_CONSTANT) LAUNCH_BRP(GF_DEPTH_U8, GF_BORDER_CONSTANT); else LAUNCH_BRP(GF_DEPTH_U8, GF_BORDER_REPLICATE); }
         else                      { if (border == GF_BORDER_CONSTANT) LAUNCH_BRP(GF_DEPTH_U16, GF_BORDER_CONSTANT); else LAUNCH_BRP(GF_DEPTH_U16, GF_BORDER_REPLICATE); }
 #undef LAUNCH_BRP
