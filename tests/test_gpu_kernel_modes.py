@@ -117,3 +117,28 @@ def test_modes_fused_blend_equals_separate_passes(gpu, mode, dtype, tdtype):
         for b in range(3):
             cv.blend_accumulate(remapped[4 * g + b], acc, 1 / 3, b == 0)
         assert torch.equal(fused[g], cv.blend_finalize(acc, tdtype)), (mode, g)
+
+
+def test_modes_mixed_tiles_wide_angle(gpu, orc, mode):
+    """A 65 degree yaw: part of the output looks behind the virtual camera (_w <= 0), part beyond the lens table, part
+    is ordinary -- tiles of all three kinds (polynomial path, per-pixel table path, exact path) meet in one frame."""
+    from gyroflow_amd import cv, _lib
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(99)
+    sw, sh, dw, dh = 1280, 720, 1400, 800
+    K = np.array([[600., 0, 640], [0, 600., 360], [0, 0, 1]]); D = [0.03, 0.02, -0.01, 0.002]
+    P = np.array([[520., 0, 700], [0, 520., 400], [0, 0, 1]])
+    for ang in ((0, 65, 0), (10, -50, 20)):
+        R = Rotation.from_euler("zyx", ang, degrees=True).as_matrix()
+        frame = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, (dw, dh), orc.CV_16SC2)
+        g1, g2 = cv.fisheye_initUndistortRectifyMap(K, D, R, P, (dw, dh), cv.CV_16SC2, device=gpu)
+        diff = np.abs(_q5(g1.cpu().numpy(), g2.cpu().numpy()) - _q5(o1, o2))
+        assert diff.max() <= 1 and (diff != 0).mean() < 1e-5, (ang, int(diff.max()), float((diff != 0).mean()))
+        src = torch.from_numpy(frame).to(gpu)
+        xf = cv.xforms_to_device(_lib.xform_to_array(_lib.make_frame_xform(K, R, P))[None], gpu)
+        got = cv.undistort_rotate(src, D, xf, (dw, dh), borderMode=0, borderValue=(1, 2, 3)).reshape(dh, dw, 3)
+        assert torch.equal(got, cv.remap(src, g1, g2, cv.INTER_LINEAR, borderMode=0, borderValue=(1, 2, 3)))
+        same = (g1.cpu().numpy() == o1).all(-1) & (g2.cpu().numpy() == o2)
+        want = orc.remap_linear(frame, o1, o2, borderMode=0, borderValue=(1, 2, 3))
+        np.testing.assert_array_equal(got.cpu().numpy()[same], want[same])
