@@ -160,7 +160,8 @@ def main():
                        "frames_per_step_per_gpu": B, "sharding": "contiguous frame ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "k_undistort_rotate", "kernel_ms": kernel_ms,
+                         "kernel": {"direct": "k_undistort_rotate", "rl": "k_undistort_rotate_rl"}.get(os.environ.get("GF_K1", "rp"), "k_undistort_rotate_rp"),
+                         "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "checksum": checksum,
         }
