@@ -473,7 +473,7 @@ template <> struct PixT<GF_DEPTH_U16> { typedef uint16_t T; };
 
 // One bilinear output pixel, cv::remapBilinear semantics (imgwarp.cpp), any border case.  (sx, sy) are the map's
 // int16 coordinates, a = fy*32 + fx.  Returns false when the pixel must be left untouched (BORDER_TRANSPARENT
-// outside).  This is the general (slow) path; interior pixels go through interp4_fast_*.
+// outside).  This is the general (slow) path; interior pixels go through interp_u8_interior / interp_u16_interior.
 struct Px3 { int c0, c1, c2, ok; };
 
 template <int DEPTH, int BORDER>
