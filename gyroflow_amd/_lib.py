@@ -56,6 +56,7 @@ SIGNATURES = {
     "gf_host_plain_slerp": [_dp, _sz, _d, _dp],
     "gf_host_rot_between": [_dp, _dp, _sz, _dp],
     "gf_get_cubic_table": [_vp],
+    "gf_get_rp_table": [_dp],
     "gf_lens_scale_host": [_dp, _dp, _sz, _dp],
 }
 
@@ -140,6 +141,13 @@ def make_frame_xform(K, R, P):
 
 def xform_to_array(xf):
     return np.frombuffer(bytes(xf), dtype=np.float64).copy()
+
+
+def rp_table():
+    """Host: the RP engine's constants (M [8,8], nodes [8], row weights [64,8])."""
+    out = np.empty(8 * 8 + 8 + 64 * 8, np.float64)
+    check(load().gf_get_rp_table(out.ctypes.data_as(_dp)))
+    return out[:64].reshape(8, 8), out[64:72], out[72:].reshape(64, 8)
 
 
 def lens_scale_host(D, t):

@@ -2091,6 +2091,13 @@ GF_API int gf_get_cubic_table(int16_t* out_host)
     return GF_OK;
 }
 
+GF_API int gf_get_rp_table(double* out_host)
+{
+    if (!out_host) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_get_rp_table");
+    build_rp_table(out_host);
+    return GF_OK;
+}
+
 GF_API int gf_lens_scale_host(const double D_host[4], const double* t_host, size_t n, double* out_host)
 {
     if (!D_host || !t_host || !out_host) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_lens_scale_host");

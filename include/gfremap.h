@@ -183,6 +183,12 @@ GF_API long long gf_host_interp_orientations(const double* times_host, const dou
 GF_API int gf_host_plain_slerp(const double* quats_host, size_t n, double alpha, double* out_host);
 GF_API int gf_host_rot_between(const double* q1_host, const double* q2_host, size_t n, double* out_host);
 
+/* Test hook (no counterpart in the reference): the constant table of the RP coordinate engine, GF_RP_TABLE_DOUBLES doubles:
+ * the 8 x 8 inverse Vandermonde matrix of the Chebyshev nodes (row-major), the 8 nodes, and the 64 x 8 Lagrange weights of
+ * the tile rows.  Host only. */
+#define GF_RP_TABLE_DOUBLES (8*8 + 8 + 64*8)
+GF_API int gf_get_rp_table(double* out_host);
+
 /* HOST (no GPU work): the kernels' table approximation of the radial scale S(t) = theta_d(atan sqrt t)/sqrt t of
  * cv::fisheye::initUndistortRectifyMap, evaluated exactly as on the device, for n values t = x^2 + y^2 in [0, 255)
  * (NaN outside: there the kernels use the exact formula).  Lets CPU tests bound the table's error. */

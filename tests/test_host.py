@@ -193,7 +193,7 @@ def test_golden_quaternion_fixtures():
 
 
 def test_lens_table_accuracy():
-    """The kernels evaluate the lens model's radial scale S(t) = theta_d(atan sqrt t)/sqrt t from a 512-piece degree-5
+    """The kernels evaluate the lens model's radial scale S(t) = theta_d(atan sqrt t)/sqrt t from a 256-piece degree-6
     table (gfremap.hip).  Against an 80-bit evaluation of the formula, the distorted radius theta_d = sqrt(t) S(t) (the
     quantity that is multiplied by the focal length, ~2000 px) must agree to 3e-14 absolute on the whole table range
     t in [0, 255), for every committed preset's coefficients and for D = 0: < 1e-10 px on the map coordinates (the
@@ -344,3 +344,31 @@ def test_quaternion_host_code_matches_python_helpers():
     np.testing.assert_allclose(sm, np.array(want), rtol=0, atol=1e-13)
     far = quat.single_slerp([1, 0, 0, 0], [0, 1, 0, 0], 0.5)
     np.testing.assert_allclose(far, [0.70710678, 0.70710678, 0, 0], atol=1e-8)      # SURVEY.md 8c verified value
+
+
+def test_rp_table_and_interpolation_error():
+    """Constants of the RP coordinate engine (gfremap.hip: build_rp_table) and the accuracy claim behind its tile guard:
+    M inverts the Vandermonde matrix of the 8 Chebyshev nodes, the row weights are the Lagrange basis at the 64 tile rows
+    (partition of unity, exact on polynomials up to degree 7), and the tensor-product interpolant of a function whose
+    nearest singularity is 8 half-tiles away (the guard's limit) is good to 1e-9 relative -- 1e-13 at 55 half-tiles,
+    a 1080p frame's geometry."""
+    from gyroflow_amd import _lib
+    M, z, Ly = _lib.rp_table()
+    assert np.allclose(np.sort(z), np.sort(np.cos(np.pi * (2 * np.arange(8) + 1) / 16)), atol=1e-16)
+    V = z[:, None] ** np.arange(8)[None, :]
+    assert np.abs(M @ V - np.eye(8)).max() < 1e-12
+    eta = (np.arange(64) - 31.5) / 32
+    assert np.abs(Ly.sum(1) - 1).max() < 1e-14
+    for d in range(8):
+        assert np.abs(Ly @ z ** d - eta ** d).max() < 1e-13
+    # the kernel's pipeline in numpy: node values -> per node row coefficients (M) -> per tile row (Ly) -> Horner in z
+    zz = (np.arange(64) - 31.5) / 32
+    for dist, tol in ((8.0, 1e-9), (55.0, 1e-13)):
+        def G(x, y):                      # analytic, singular at x^2 + y^2 = -dist^2 (x, y in half tiles): like 1/sqrt(q)
+            return 1.0 / np.sqrt(1.0 + ((x + 0.3) ** 2 + (y - 0.2) ** 2) / dist ** 2)
+        nodes = G(z[None, :], z[:, None])                                  # [node row m][node column a]
+        C2 = nodes @ M.T                                                   # [m][power]
+        C = Ly @ C2                                                        # [tile row][power]
+        got = sum(C[:, k][:, None] * zz[None, :] ** k for k in range(8))
+        want = G(zz[None, :], eta[:, None])
+        assert np.abs(got / want - 1).max() < tol, (dist, np.abs(got / want - 1).max())
