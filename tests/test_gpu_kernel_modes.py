@@ -142,3 +142,12 @@ def test_modes_mixed_tiles_wide_angle(gpu, orc, mode):
         same = (g1.cpu().numpy() == o1).all(-1) & (g2.cpu().numpy() == o2)
         want = orc.remap_linear(frame, o1, o2, borderMode=0, borderValue=(1, 2, 3))
         np.testing.assert_array_equal(got.cpu().numpy()[same], want[same])
+
+
+def test_set_kernel_mode_rejects_unknown_mode(gpu):
+    from gyroflow_amd import _lib
+    with pytest.raises(_lib.GfError) as e:
+        _lib.set_kernel_mode(gpu.index or 0, 17)
+    assert "unknown mode" in str(e.value)
+    lib = _lib.load()
+    assert lib.gf_ctx_set_kernel_mode(None, _lib.KERNEL_RP) != 0          # null ctx
