@@ -4,7 +4,8 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-A step = one launch of the fused kernel (gf_undistort_rotate_c3) over one batch of B synthetic frames that are
+A step = one launch of the fused kernel (gf_undistort_rotate_c3; for --config c4 followed by the superview launch,
+gf_superview_cubic_u8c3) over one batch of B synthetic frames that are
 already resident in HBM (mode M1 of BASELINE.md); every frame of every step uses its own rotation from the real
 per-frame quaternion trace (tests/golden/quats_gyroflow_sample.npz).  Frames are independent, so with N ranks each
 rank works through its own contiguous shard of the trace with no data-path collective (weak scaling: fixed work
@@ -31,14 +32,20 @@ CONFIGS = {
     "c2": ("hero8_27k_43", 2704, 2028, 1920, 1080, "u8", "C2 2704x2028 u8 -> 1920x1080"),
     "c3": ("hero7_4k_169", 3840, 2160, 3840, 2160, "u8", "C3 3840x2160 4K u8 -> 3840x2160"),
     "c5": ("hero9_5k_169", 5312, 2988, 5312, 2988, "u16", "C5 5312x2988 u16 -> 5312x2988 (no blend)"),
+    # C4: the fused remap to 2880x2160, then NonlinearStretch (bicubic) to 3840x2160 -- two launches per step
+    "c4": ("hero9_4k_43", 4000, 3000, 2880, 2160, "u8", "C4 4000x3000 u8 -> 2880x2160 -> superview 3840x2160"),
 }
+STRETCH = {"c4": (3840, 2160)}
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
 def algorithmic_bytes_per_frame(cfg):
     _, iw, ih, ow, oh, dt, _ = CONFIGS[cfg]
     esz = 1 if dt == "u8" else 2
-    return iw * ih * 3 * esz + ow * oh * 3 * esz      # source read once + destination written once; maps = 0
+    b = iw * ih * 3 * esz + ow * oh * 3 * esz         # source read once + destination written once; maps = 0
+    if cfg in STRETCH:                                # the intermediate frame is read again, the stretched frame written
+        b += ow * oh * 3 * esz + STRETCH[cfg][0] * STRETCH[cfg][1] * 3 * esz
+    return b
 
 
 def load_quats():
@@ -54,12 +61,18 @@ def cpu_baseline(cfg, cal, quats, frames, n_frames, threads):
     _, iw, ih, ow, oh, dt, _ = CONFIGS[cfg]
     t_map = t_remap = 0.0
     dst = None
+    ns = None
+    if cfg in STRETCH:
+        from gyroflow_amd import NonlinearStretch
+        ns = NonlinearStretch((ow, oh), STRETCH[cfg]); ns.recompute_maps()
     for i in range(n_frames):
         K, D, R, P, od = cal._frame_matrices(1.0, (ow, oh), (iw, ih), quats[i % len(quats)], None, True)
         t0 = time.perf_counter()
         m1, m2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, od, orc.CV_16SC2)
         t1 = time.perf_counter()
         dst = orc.remap_linear(frames[i % len(frames)], m1, m2, dst=dst, nthreads=threads)
+        if ns is not None:
+            orc.remap_cubic(dst, ns.map1, ns.map2, nthreads=threads)
         t2 = time.perf_counter()
         t_map += t1 - t0
         t_remap += t2 - t1
@@ -116,8 +129,18 @@ def main():
     dst = torch.empty((B, oh, ow, 3), dtype=src.dtype, device=dev)
     border = cv.BORDER_CONSTANT if args.border == "constant" else cv.BORDER_REPLICATE
 
-    def step(s):
-        cv.undistort_rotate(src, cal.D, xf_dev[s], (ow, oh), dst=dst, borderMode=border)
+    if args.config in STRETCH:
+        from gyroflow_amd import NonlinearStretch
+        ns = NonlinearStretch((ow, oh), STRETCH[args.config]); ns.recompute_maps()
+        mx = torch.from_numpy(ns.map1[0].copy()).to(dev); my = torch.from_numpy(ns.map2[:, 0].copy()).to(dev)
+        out2 = torch.empty((B, STRETCH[args.config][1], STRETCH[args.config][0], 3), dtype=src.dtype, device=dev)
+
+        def step(s):
+            cv.undistort_rotate(src, cal.D, xf_dev[s], (ow, oh), dst=dst, borderMode=border)
+            cv.superview_cubic(dst, mx, my, dst=out2)
+    else:
+        def step(s):
+            cv.undistort_rotate(src, cal.D, xf_dev[s], (ow, oh), dst=dst, borderMode=border)
 
     for s in range(W):
         step(s)
@@ -160,7 +183,8 @@ def main():
                        "frames_per_step_per_gpu": B, "sharding": "contiguous frame ranges, no collective"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": {"direct": "k_undistort_rotate", "rl": "k_undistort_rotate_rl"}.get(os.environ.get("GF_K1", "rp"), "k_undistort_rotate_rp"),
+                         "kernel": {"direct": "k_undistort_rotate", "rl": "k_undistort_rotate_rl"}.get(os.environ.get("GF_K1", "rp"), "k_undistort_rotate_rp")
+                                   + (" + k_superview_cubic" if args.config in STRETCH else ""),
                          "kernel_ms": kernel_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch},
             "checksum": checksum,
@@ -168,7 +192,7 @@ def main():
         if world == 1:
             n_cpu = args.cpu_frames
             if n_cpu < 0:
-                n_cpu = {"c1": 400, "c2": 400, "c3": 96, "c5": 36}[args.config]      # about 10 s of CPU work
+                n_cpu = {"c1": 400, "c2": 400, "c3": 96, "c4": 48, "c5": 36}[args.config]      # about 10 s of CPU work
             if n_cpu > 0:
                 threads = min(16, os.cpu_count() or 1)
                 out["cpu_baseline"] = cpu_baseline(args.config, cal, quats, ring, n_cpu, threads)
