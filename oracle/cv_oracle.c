@@ -93,9 +93,12 @@ ORC_API int orc_compute_iR(const double* R, const double* P, double* iR)
 /* cv::fisheye::initUndistortRectifyMap (CV_16SC2 or CV_32FC1)                            */
 /*  flags bit0: Q2 -- apply the `_w <= 0 -> +-inf` branch of newer 4.5.x builds.          */
 /*  iR_in: when non-NULL use it instead of inverting P*R (lets tests share one inverse).  */
-ORC_API int orc_fisheye_maps(const double* K, const double* D, const double* R, const double* P,
+/*  nthreads: rows are independent (each starts from i*iR[.1] + iR[.2]), so striping them over threads
+ *  gives the same bits; OpenCV itself runs this loop on one thread (nthreads = 1 is the faithful
+ *  timing, > 1 is bench.py's "best CPU" figure).                                          */
+static int fisheye_maps_impl(const double* K, const double* D, const double* R, const double* P,
                              const double* iR_in, int width, int height, int m1type, int flags,
-                             void* map1, size_t map1_step, void* map2, size_t map2_step)
+                             void* map1, size_t map1_step, void* map2, size_t map2_step, int nthreads)
 {
     if (m1type != ORC_CV_16SC2 && m1type != ORC_CV_32FC1) return -2;
     const double f0 = K[0], f1 = K[4], c0 = K[2], c1 = K[5];
@@ -104,7 +107,9 @@ ORC_API int orc_fisheye_maps(const double* K, const double* D, const double* R, 
     if (iR_in) memcpy(iR, iR_in, sizeof iR);
     else if (orc_compute_iR(R, P, iR)) return -1;
     const int wcheck = flags & 1;
+    if (nthreads < 1) nthreads = 1;
 
+    #pragma omp parallel for num_threads(nthreads) schedule(static) if(nthreads > 1)
     for (int i = 0; i < height; ++i) {
         float* m1f = (float*)((char*)map1 + (size_t)i * map1_step);
         float* m2f = (float*)((char*)map2 + (size_t)i * map2_step);
@@ -142,6 +147,20 @@ ORC_API int orc_fisheye_maps(const double* K, const double* D, const double* R, 
         }
     }
     return 0;
+}
+
+ORC_API int orc_fisheye_maps(const double* K, const double* D, const double* R, const double* P,
+                             const double* iR_in, int width, int height, int m1type, int flags,
+                             void* map1, size_t map1_step, void* map2, size_t map2_step)
+{
+    return fisheye_maps_impl(K, D, R, P, iR_in, width, height, m1type, flags, map1, map1_step, map2, map2_step, 1);
+}
+
+ORC_API int orc_fisheye_maps_mt(const double* K, const double* D, const double* R, const double* P,
+                                const double* iR_in, int width, int height, int m1type, int flags,
+                                void* map1, size_t map1_step, void* map2, size_t map2_step, int nthreads)
+{
+    return fisheye_maps_impl(K, D, R, P, iR_in, width, height, m1type, flags, map1, map1_step, map2, map2_step, nthreads);
 }
 
 /* cv::convertMaps(CV_32FC1, CV_32FC1 -> CV_16SC2 + CV_16UC1), nninterpolate=false        */

@@ -68,8 +68,9 @@ def compute_iR(R, P):
     return out.reshape(3, 3)
 
 
-def fisheye_init_undistort_rectify_map(K, D, R, P, size, m1type, iR=None, wcheck=True):
-    """cv2.fisheye.initUndistortRectifyMap(K, D, R, P, size, m1type) -> (map1, map2)."""
+def fisheye_init_undistort_rectify_map(K, D, R, P, size, m1type, iR=None, wcheck=True, nthreads=1):
+    """cv2.fisheye.initUndistortRectifyMap(K, D, R, P, size, m1type) -> (map1, map2).
+    nthreads > 1 stripes the rows over threads (same bits; OpenCV runs this loop on one thread)."""
     w, h = int(size[0]), int(size[1])
     K = _d9(K); D4 = np.zeros(4); Df = np.asarray(D, np.float64).reshape(-1); D4[:Df.size] = Df
     R = _d9(np.eye(3) if R is None else R); P = _d9(np.asarray(P, np.float64)[:, :3])
@@ -80,8 +81,8 @@ def fisheye_init_undistort_rectify_map(K, D, R, P, size, m1type, iR=None, wcheck
     else:
         raise ValueError("m1type")
     iRp = _p(_d9(iR)) if iR is not None else None
-    rc = lib().orc_fisheye_maps(_p(K), _p(D4), _p(R), _p(P), iRp, w, h, m1type, 1 if wcheck else 0,
-                                _p(m1), C.c_size_t(m1.strides[0]), _p(m2), C.c_size_t(m2.strides[0]))
+    rc = lib().orc_fisheye_maps_mt(_p(K), _p(D4), _p(R), _p(P), iRp, w, h, m1type, 1 if wcheck else 0,
+                                   _p(m1), C.c_size_t(m1.strides[0]), _p(m2), C.c_size_t(m2.strides[0]), int(nthreads))
     if rc:
         raise ValueError("orc_fisheye_maps rc=%d" % rc)
     return m1, m2

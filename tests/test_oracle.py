@@ -191,6 +191,18 @@ def test_remap_threads_agree(orc):
     np.testing.assert_array_equal(a, b)
 
 
+def test_fisheye_maps_threads_agree(orc):
+    """Rows of initUndistortRectifyMap are independent: the row-striped variant (bench.py's "best CPU" leg) gives the same bits."""
+    K = np.array([[420.0, 0, 318.5], [0, 421.0, 241.25], [0, 0, 1]]); D = [0.05, -0.01, 0.02, -0.01]
+    a = np.deg2rad(4.0)
+    R = np.array([[np.cos(a), -np.sin(a), 0.01], [np.sin(a), np.cos(a), -0.02], [0, 0, 1.0]])
+    P = np.array([[400.0, 0, 320], [0, 400.0, 180], [0, 0, 1]])
+    for mt in (orc.CV_16SC2, orc.CV_32FC1):
+        s1, s2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, (333, 187), mt)
+        t1, t2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, (333, 187), mt, nthreads=5)
+        np.testing.assert_array_equal(s1, t1); np.testing.assert_array_equal(s2, t2)
+
+
 # ------------------------------------------------------------------ bicubic remap
 def test_remap_cubic_known_answers(orc):
     rng = np.random.default_rng(4)

@@ -154,6 +154,54 @@ static void run(const uint8_t* buf, uint32_t* out, int lane_stride, int rowstep,
     printf("  width %2d B  lane stride %3d B : %6.2f ns = %5.1f cycles per wave-instr per CU  (%5.1f B/clk/CU)\n", W, lane_stride, ns, ns*2.4, 64.0*W/(ns*2.4));
 }
 
+// Aligned variant: every lane address is a multiple of ALIGN bytes (ALIGN = 4 or the access width), vector loads of W bytes.
+template <int W> struct AlT;
+template <> struct AlT<4>  { typedef uint32_t T; };
+template <> struct AlT<8>  { typedef u2 T; };
+template <> struct AlT<12> { typedef u3 T; };
+template <> struct AlT<16> { typedef u4 T; };
+template <int W, int ALIGN> __device__ __forceinline__ uint32_t ld_al(const uint8_t* p)
+{
+    struct alignas(ALIGN) V { uint32_t v[W/4]; };
+    const V x = *(const V*)p;
+    uint32_t r = 0;
+#pragma unroll
+    for (int k = 0; k < W/4; k++) r ^= x.v[k];
+    return r;
+}
+template <int W, int ALIGN>
+__global__ void __launch_bounds__(256) k_gather_al(const uint8_t* __restrict__ base, uint32_t* out, int lane_stride, int rowstep, int iters, uint32_t region)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t acc = 0;
+    uint32_t off0 = lane*lane_stride + wave*rowstep*8 + (blockIdx.x & 7)*64;
+    for (int it = 0; it < iters; it++) {
+        uint32_t o = off0 + (it & 15)*ALIGN;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t a = o + k*rowstep;
+            a = a < region ? a : a - region;
+            acc ^= ld_al<W, ALIGN>(base + a);
+        }
+    }
+    out[blockIdx.x*256 + threadIdx.x] = acc;
+}
+template <int W, int ALIGN>
+static void run_al(const uint8_t* buf, uint32_t* out, int lane_stride, int rowstep, uint32_t region)
+{
+    const int iters = 2000, blocks = 256*8;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_gather_al<W, ALIGN>), dim3(blocks), dim3(256), 0, 0, buf, out, lane_stride, rowstep, 10, region);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_gather_al<W, ALIGN>), dim3(blocks), dim3(256), 0, 0, buf, out, lane_stride, rowstep, iters, region);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr_per_cu = (double)blocks*4*iters*8/256.0;
+    const double ns = ms*1e6/instr_per_cu;
+    printf("  aligned %2d  width %2d B  lane stride %3d B : %6.2f ns = %5.1f cycles (2.1 GHz) per wave-instr per CU  (%5.1f B/clk/CU)\n", ALIGN, W, lane_stride, ns, ns*2.1, 64.0*W/(ns*2.1));
+}
+
 int main()
 {
     const uint32_t region = 1u << 20;      // 1 MiB: L2 resident, rows spread like an image tile
@@ -184,6 +232,12 @@ int main()
         CK(hipFree(sink));
         CK(hipFree(b2));
     }
+    printf("aligned loads (cache resident)\n");
+    run_al<4, 4>(buf, out, 4, rowstep, region);   run_al<4, 4>(buf, out, 12, rowstep, region);  run_al<4, 4>(buf, out, 64, rowstep, region);
+    run_al<8, 4>(buf, out, 12, rowstep, region);  run_al<8, 8>(buf, out, 8, rowstep, region);   run_al<8, 8>(buf, out, 16, rowstep, region);
+    run_al<12, 4>(buf, out, 12, rowstep, region); run_al<12, 4>(buf, out, 16, rowstep, region);
+    run_al<16, 4>(buf, out, 12, rowstep, region); run_al<16, 4>(buf, out, 16, rowstep, region); run_al<16, 16>(buf, out, 16, rowstep, region);
+    run_al<16, 16>(buf, out, 32, rowstep, region);
     printf("partial exec masks, width 8, lane stride 12\n");
     for (int a : {16, 12, 8, 4, 2, 1}) run<8>(buf, out, 12, rowstep, region, a);
     return 0;
