@@ -202,6 +202,42 @@ static void run_al(const uint8_t* buf, uint32_t* out, int lane_stride, int rowst
     printf("  aligned %2d  width %2d B  lane stride %3d B : %6.2f ns = %5.1f cycles (2.1 GHz) per wave-instr per CU  (%5.1f B/clk/CU)\n", ALIGN, W, lane_stride, ns, ns*2.1, 64.0*W/(ns*2.1));
 }
 
+// K1-like footprint, cache resident: a wave-load covers R source rows (64/R lanes each, lane stride 12 B, aligned 12-byte loads),
+// optionally with the row advancing by one every `slope` lanes (a rolled camera).  Cost per wave-instruction vs R.
+template <int W>
+__global__ void __launch_bounds__(256) k_rows(const uint8_t* __restrict__ base, uint32_t* out, int R, int rowstep, int iters, uint32_t region, int slope)
+{
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned lpr = 64u/(unsigned)R, lr = lane/lpr, lc = lane%lpr;
+    uint32_t acc = 0;
+    uint32_t off0 = lr*(unsigned)rowstep + lc*12u + (slope ? (lc/(unsigned)slope)*(unsigned)rowstep : 0u) + wave*(unsigned)rowstep*(unsigned)R + (blockIdx.x & 7)*64;
+    for (int it = 0; it < iters; it++) {
+        uint32_t o = off0 + (it & 15)*4;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            uint32_t a = o + (k & 1)*rowstep + (k >> 1)*4;
+            a = a < region ? a : a - region;
+            acc ^= ld_al<W, 4>(base + a);
+        }
+    }
+    out[blockIdx.x*256 + threadIdx.x] = acc;
+}
+template <int W>
+static void run_rows(const uint8_t* buf, uint32_t* out, int R, int rowstep, uint32_t region, int slope)
+{
+    const int iters = 2000, blocks = 256*8;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_rows<W>), dim3(blocks), dim3(256), 0, 0, buf, out, R, rowstep, 10, region, slope);
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_rows<W>), dim3(blocks), dim3(256), 0, 0, buf, out, R, rowstep, iters, region, slope);
+    CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double instr_per_cu = (double)blocks*4*iters*8/256.0;
+    const double ns = ms*1e6/instr_per_cu;
+    printf("  rows per wave-load %2d (slope %2d)  width %2d B : %6.2f ns = %5.1f cycles (2.1 GHz) per wave-instr per CU\n", R, slope, W, ns, ns*2.1);
+}
+
 int main()
 {
     const uint32_t region = 1u << 20;      // 1 MiB: L2 resident, rows spread like an image tile
@@ -238,6 +274,11 @@ int main()
     run_al<12, 4>(buf, out, 12, rowstep, region); run_al<12, 4>(buf, out, 16, rowstep, region);
     run_al<16, 4>(buf, out, 12, rowstep, region); run_al<16, 4>(buf, out, 16, rowstep, region); run_al<16, 16>(buf, out, 16, rowstep, region);
     run_al<16, 16>(buf, out, 32, rowstep, region);
+    printf("K1-like footprints (aligned, cache resident)\n");
+    for (int R : {1, 2, 4, 8, 16}) run_rows<12>(buf, out, R, rowstep, region, 0);
+    for (int R : {1, 2, 4, 8}) run_rows<12>(buf, out, R, rowstep, region, 4);
+    for (int R : {1, 4}) run_rows<4>(buf, out, R, rowstep, region, 0);
+    for (int R : {1, 4}) run_rows<16>(buf, out, R, rowstep, region, 0);
     printf("partial exec masks, width 8, lane stride 12\n");
     for (int a : {16, 12, 8, 4, 2, 1}) run<8>(buf, out, 12, rowstep, region, a);
     return 0;
