@@ -1,7 +1,8 @@
 """FisheyeCalibrator: lens model holder + per-frame map generation, on MI355X.
 
 Host-side mirror of the hot-path part of the reference class of the same name
-(/root/reference/calibrate_video.py:33): preset loading (:520-587, :642-652) and get_maps (:330-384).
+(/root/reference/calibrate_video.py:33): preset loading (:520-587, :642-652), get_maps (:330-384) and
+undistort_image (:296-328).
 The chessboard calibration itself (cv2.fisheye.calibrate, :137-259) is out of scope.
 
 get_maps() keeps the reference signature and returns the same (map1, map2) pair -- as CUDA tensors -- by calling
@@ -123,6 +124,21 @@ class FisheyeCalibrator:
         with open(filename, "r") as infile:
             presets = json.load(infile)
         return self.load_calibration_data(presets, printinfo)
+
+    # ------------------------------------------------------------------ one-shot undistortion (:296-328)
+    def undistort_image(self, img, fov_scale=1.0, device=None):
+        """Undistort one image with the fisheye model (reference: calibrate_video.py:296-328): new camera matrix from
+        cv2.fisheye.estimateNewCameraMatrixForUndistortRectify (:314, sets self.new_K), CV_16SC2 maps with R = I (:322),
+        bilinear remap with a constant black border (:325).  The reference first re-runs the chessboard calibration
+        (compute_calibration, out of scope here): K and D are taken as loaded.  numpy in -> numpy out, tensor in -> tensor out."""
+        img_dim = (int(img.shape[1]), int(img.shape[0]))
+        scaled_K = self.K * img_dim[0] / self.calib_dimension[0]
+        scaled_K[2][2] = 1.0
+        new_K = cv.fisheye_estimateNewCameraMatrixForUndistortRectify(scaled_K, self.D, img_dim, np.eye(3), fov_scale=fov_scale,
+                                                                      device=device)
+        self.new_K = new_K
+        map1, map2 = cv.fisheye_initUndistortRectifyMap(scaled_K, self.D, np.eye(3), new_K, img_dim, cv.CV_16SC2, device=device)
+        return cv.remap(img, map1, map2, cv.INTER_LINEAR, borderMode=cv.BORDER_CONSTANT)
 
     # ------------------------------------------------------------------ per-frame parameters (:341-370)
     def _frame_matrices(self, fov_scale, output_dim, new_img_dim, quat, focalCenter, original_stretched):

@@ -336,6 +336,38 @@ def fisheye_undistortPoints(distorted, K, D, R=None, P=None, device=None):
     return res if batch else res[0].reshape(lead + (n_pts, 2))
 
 
+def fisheye_estimateNewCameraMatrixForUndistortRectify(K, D, image_size, R, P=None, balance=0.0, new_size=None, fov_scale=1.0,
+                                                        device=None):
+    """cv2.fisheye.estimateNewCameraMatrixForUndistortRectify(K, D, image_size, R, fov_scale=...) (calibrate_video.py:314).
+
+    OpenCV 4.5 algorithm: the mid-points of the four image edges, (w/2, 0) (w, h/2) (w/2, h) (0, h/2) with *integer* w/2 and
+    h/2, go through fisheye::undistortPoints (here: the GPU kernel behind fisheye_undistortPoints); the focal length is the
+    one that maps the farthest (balance = 0) or nearest (balance = 1) of them onto the image border around their centre of
+    mass, divided by fov_scale; the y axis is handled in units of the aspect ratio fx/fy.  Host float64 arithmetic in
+    OpenCV's operation order.  Returns the 3x3 new camera matrix (float64)."""
+    Km = np.asarray(K, np.float64).reshape(3, 3)
+    w, h = int(image_size[0]), int(image_size[1])
+    balance = min(max(float(balance), 0.0), 1.0)
+    pts = np.array([[w // 2, 0], [w, h // 2], [w // 2, h], [0, h // 2]], np.float64)
+    und = fisheye_undistortPoints(pts[None], Km, D, R=R, device=device)[0]
+    cn = [((und[0, 0] + und[1, 0]) + und[2, 0] + und[3, 0]) / 4.0, ((und[0, 1] + und[1, 1]) + und[2, 1] + und[3, 1]) / 4.0]
+    aspect_ratio = Km[0, 0] / Km[1, 1]
+    cn[1] *= aspect_ratio                                     # convert to identity ratio
+    py = und[:, 1] * aspect_ratio
+    minx, maxx, miny, maxy = und[:, 0].min(), und[:, 0].max(), py.min(), py.max()
+    f1 = w * 0.5 / (cn[0] - minx); f2 = w * 0.5 / (maxx - cn[0])
+    f3 = h * 0.5 * aspect_ratio / (cn[1] - miny); f4 = h * 0.5 * aspect_ratio / (maxy - cn[1])
+    fmin, fmax = min(f1, f2, f3, f4), max(f1, f2, f3, f4)
+    f = balance * fmin + (1.0 - balance) * fmax
+    f *= 1.0 / fov_scale if fov_scale > 0 else 1.0
+    new_f = [f, f / aspect_ratio]                             # restore aspect ratio
+    new_c = [-cn[0] * f + w * 0.5, (-cn[1] * f + (h * aspect_ratio) * 0.5) / aspect_ratio]
+    if new_size is not None and int(new_size[0]) * int(new_size[1]) > 0:
+        rx, ry = new_size[0] / float(w), new_size[1] / float(h)
+        new_f = [new_f[0] * rx, new_f[1] * ry]; new_c = [new_c[0] * rx, new_c[1] * ry]
+    return np.array([[new_f[0], 0.0, new_c[0]], [0.0, new_f[1], new_c[1]], [0.0, 0.0, 1.0]])
+
+
 def cubic_table():
     """Host copy of the library's 1024x16 int16 bicubic table (no GPU needed)."""
     out = np.empty((1024, 16), np.int16)

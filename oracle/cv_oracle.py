@@ -169,6 +169,39 @@ def undistort_points(pts, K, D, R=None, P=None):
     return out.reshape(shp)
 
 
+def estimate_new_camera_matrix(K, D, image_size, R=None, balance=0.0, new_size=None, fov_scale=1.0):
+    """cv2.fisheye.estimateNewCameraMatrixForUndistortRectify (reference call: calibrate_video.py:314), restated from the OpenCV
+    4.5 source as remembered -- PARITY UNPINNED (nothing in the reference tree holds an output of it).  Quirks restated: the four
+    edge mid-points use integer w/2, h/2; cn[1] and the points' y are scaled by fx/fy; balance clamps to [0, 1]; fov_scale <= 0
+    means 1.  Written independently of gyroflow_amd.cv's version (scalar loops, CPU undistort_points)."""
+    K = np.asarray(K, np.float64).reshape(3, 3)
+    w, h = int(image_size[0]), int(image_size[1])
+    balance = min(max(float(balance), 0.0), 1.0)
+    pts = np.array([[[w // 2, 0]], [[w, h // 2]], [[w // 2, h]], [[0, h // 2]]], np.float64)
+    und = undistort_points(pts, K, D, R=R).reshape(4, 2)
+    sx = sy = 0.0
+    for i in range(4):
+        sx += und[i, 0]; sy += und[i, 1]
+    cn0, cn1 = sx / 4.0, sy / 4.0
+    ar = K[0, 0] / K[1, 1]
+    cn1 *= ar
+    minx = miny = float("inf"); maxx = maxy = -float("inf")
+    for i in range(4):
+        y = und[i, 1] * ar
+        miny = min(miny, y); maxy = max(maxy, y); minx = min(minx, und[i, 0]); maxx = max(maxx, und[i, 0])
+    f1 = w * 0.5 / (cn0 - minx); f2 = w * 0.5 / (maxx - cn0); f3 = h * 0.5 * ar / (cn1 - miny); f4 = h * 0.5 * ar / (maxy - cn1)
+    fmin = min(f1, min(f2, min(f3, f4))); fmax = max(f1, max(f2, max(f3, f4)))
+    f = balance * fmin + (1.0 - balance) * fmax
+    f *= (1.0 / fov_scale) if fov_scale > 0 else 1.0
+    nf0, nf1 = f, f
+    nc0, nc1 = -cn0 * f + w * 0.5, -cn1 * f + (h * ar) * 0.5
+    nf1 /= ar; nc1 /= ar
+    if new_size is not None and int(new_size[0]) * int(new_size[1]) > 0:
+        rx = new_size[0] / float(w); ry = new_size[1] / float(h)
+        nf0 *= rx; nf1 *= ry; nc0 *= rx; nc1 *= ry
+    return np.array([[nf0, 0.0, nc0], [0.0, nf1, nc1], [0.0, 0.0, 1.0]])
+
+
 def blend_accumulate(frame, acc, weight, reset):
     frame = np.ascontiguousarray(frame)
     assert acc.dtype == np.float64 and acc.flags.c_contiguous and acc.size == frame.size

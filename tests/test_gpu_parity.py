@@ -185,6 +185,30 @@ def test_fused_full_size_4k_vs_oracle(gpu, orc, golden_calls):
     assert (sh[:3] == 0).all() and (sh[:, -5:] == 0).all()
 
 
+def test_undistort_image_matches_oracle_chain(gpu, orc):
+    """FisheyeCalibrator.undistort_image (calibrate_video.py:296-328): estimateNewCameraMatrixForUndistortRectify -> maps with
+    R = I -> bilinear remap.  The new camera matrix goes through the GPU undistortPoints kernel (tan from the device libm):
+    1e-12 relative against the oracle; with the same matrix the maps obey the usual tie tolerance and pixels follow."""
+    import os
+    from conftest import GOLDEN
+    from gyroflow_amd import FisheyeCalibrator
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(os.path.join(GOLDEN, "presets", "hero8_27k_43.json"))
+    rng = np.random.default_rng(77)
+    for (w, h), fov in (((676, 507), 1.0), ((1353, 1015), 1.4)):
+        img = _rand_img(rng, h, w, np.uint8)
+        got = cal.undistort_image(img, fov_scale=fov)
+        assert isinstance(got, np.ndarray) and got.shape == img.shape
+        sK = cal.K * w / cal.calib_dimension[0]; sK[2][2] = 1.0
+        want_K = orc.estimate_new_camera_matrix(sK, cal.D, (w, h), np.eye(3), fov_scale=fov)
+        np.testing.assert_allclose(cal.new_K, want_K, rtol=1e-12, atol=1e-12)
+        o1, o2 = orc.fisheye_init_undistort_rectify_map(sK, cal.D, np.eye(3), cal.new_K, (w, h), orc.CV_16SC2)
+        want = orc.remap_linear(img, o1, o2)
+        bad = (got != want).any(axis=-1)
+        assert bad.mean() < 1e-5, "pixels differing from the oracle chain: %g" % bad.mean()
+        assert (got == 0).all(axis=-1).any() or fov <= 1.0        # zoomed out: the constant border shows
+
+
 def test_convert_maps_and_stretched_get_maps(gpu, orc, golden_calls):
     """K3 + the stretched-preset branch of get_maps (calibrate_video.py:375-380)."""
     from gyroflow_amd import cv, FisheyeCalibrator

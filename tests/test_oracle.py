@@ -245,6 +245,35 @@ def test_undistort_points_inverts_the_forward_model(orc):
     np.testing.assert_allclose(und2, und * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]], atol=1e-4)
 
 
+def test_estimate_new_camera_matrix_closed_forms(orc):
+    """estimateNewCameraMatrixForUndistortRectify (calibrate_video.py:314) on lenses with a closed form -- parity unpinned, these
+    pin the restatement to its own description: k = 0 makes undistortPoints the map r -> tan(r)."""
+    w, h, f = 640, 480, 500.0
+    K = np.array([[f, 0, w / 2], [0, f, h / 2], [0, 0, 1]])
+    P = orc.estimate_new_camera_matrix(K, np.zeros(4), (w, h), np.eye(3))
+    fx, fy = w * 0.5 / np.tan(w / 2 / f), h * 0.5 / np.tan(h / 2 / f)          # edge mid-points land on the border
+    assert fy > fx
+    np.testing.assert_allclose(P, [[fy, 0, w / 2], [0, fy, h / 2], [0, 0, 1]], rtol=1e-12)       # balance 0: the larger focal length
+    P1 = orc.estimate_new_camera_matrix(K, np.zeros(4), (w, h), np.eye(3), balance=1.0, fov_scale=2.0)
+    np.testing.assert_allclose(P1, [[fx / 2, 0, w / 2], [0, fx / 2, h / 2], [0, 0, 1]], rtol=1e-12)
+    P2 = orc.estimate_new_camera_matrix(K, np.zeros(4), (w, h), np.eye(3), balance=7.0, new_size=(320, 120))   # balance clamps to 1
+    np.testing.assert_allclose(P2, [[fx * 0.5, 0, w / 4], [0, fx * 0.25, h / 8], [0, 0, 1]], rtol=1e-12)
+    # aspect ratio fx/fy != 1: fy' = fx'/ratio, principal point stays at the centre for a centred lens
+    Ka = np.array([[f, 0, w / 2], [0, f / 1.25, h / 2], [0, 0, 1]])
+    Pa = orc.estimate_new_camera_matrix(Ka, np.zeros(4), (w, h), np.eye(3))
+    np.testing.assert_allclose(Pa[1, 1], Pa[0, 0] / 1.25, rtol=1e-13)
+    np.testing.assert_allclose(Pa[:2, 2], [w / 2, h / 2], rtol=1e-12)
+    # odd sizes: the mid-points use integer w/2, h/2, so the centre of mass is off the principal point
+    Ko = np.array([[f, 0, 320.5], [0, f, 240.5], [0, 0, 1]])
+    Po = orc.estimate_new_camera_matrix(Ko, np.zeros(4), (641, 481), np.eye(3))
+    pts = np.array([[[320, 0]], [[641, 240]], [[320, 481]], [[0, 240]]], np.float64)
+    und = orc.undistort_points(pts, Ko, np.zeros(4)).reshape(4, 2)
+    cn = und.mean(0)
+    fo = max(641 * 0.5 / (cn[0] - und[:, 0].min()), 641 * 0.5 / (und[:, 0].max() - cn[0]),
+             481 * 0.5 / (cn[1] - und[:, 1].min()), 481 * 0.5 / (und[:, 1].max() - cn[1]))
+    np.testing.assert_allclose(Po, [[fo, 0, -cn[0] * fo + 320.5], [0, fo, -cn[1] * fo + 240.5], [0, 0, 1]], rtol=1e-12)
+
+
 def test_blend_matches_numpy(orc):
     rng = np.random.default_rng(5)
     fr = [rng.integers(0, 65536, (5, 7, 3)).astype(np.uint16) for _ in range(3)]
