@@ -1114,12 +1114,24 @@ __device__ __forceinline__ void interp_u8_raw(const uint32_t* box, unsigned ru, 
 // (tid % 16, tid / 16) produces columns 4 lx .. 4 lx + 3 of tile rows ly, ly + 16, ly + 32, ly + 48.  Software pipeline with
 // one barrier per work item k: one wave (in turn) runs rp_nodes for item k + 2, all threads run rp_rows for item k + 1
 // (thread t: coefficient t % 8 of rows t / 8 and 32 + t / 8), then the pixels of item k.
+#ifdef GF_TRACE_WG   /* tools/ builds only: start time, end time (wall clock, 100 MHz) and hardware id of every workgroup of the last launch */
+__device__ unsigned long long g_wg_trace[8192][3];
+#endif
+
 template <int DEPTH, int BORDER>
 __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
                                                                 const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work)
 {
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     __shared__ RpShared S;
+#ifdef GF_TRACE_WG
+    if (threadIdx.x == 0 && blockIdx.x < 8192) {
+        unsigned hwid, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_wg_trace[blockIdx.x][0] = wall_clock64(); g_wg_trace[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hwid;
+    }
+#endif
     load_lens_table(lens, s_tab);
     constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1177,6 +1189,9 @@ __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(Rema
         }
         lds_barrier();
     }
+#ifdef GF_TRACE_WG
+    if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_trace[blockIdx.x][1] = wall_clock64();
+#endif
 }
 
 // K1-RL: RP coordinates + source taps staged through LDS (u8).  A workgroup is four consumer waves and one producer wave:
@@ -2369,6 +2384,15 @@ static int launch_fused(Ctx* c, int depth, const void* src, int sw, int sh, size
     return GF_OK;
 }
 
+
+#ifdef GF_TRACE_WG
+GF_API int gf_debug_read_wg_trace(unsigned long long* out /* [8192][3] */)      // tools/kbench prints the timeline
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_trace), sizeof(unsigned long long)*8192*3));
+    return GF_OK;
+}
+#endif
 
 GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                            void* dst, int dw, int dh, size_t dstep, size_t dframe,

@@ -18,6 +18,7 @@ for v in "$@"; do
         IFS=_ read -r _ tw th <<< "$v"
         hipcc $F -DGF_TILE_W=$tw -DGF_TILE_H=$th -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
     pairs_*) hipcc $F -DGF_COORD_PAIRS=1 -DGF_K1_WAVES=${v#pairs_} -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
+    trace)    hipcc $F -DGF_TRACE_WG -o tools/_build/lib_trace.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;   # kbench --lib prints the workgroup timeline
     both)     hipcc $F -DGF_ABL_NOMATH -DGF_ABL_NOGATHER -o tools/_build/lib_both.so gyroflow_amd/csrc/gfremap.hip ;;
   esac
 done

@@ -110,6 +110,35 @@ int main(int argc, char** argv)
     std::vector<uint8_t> hd(dframe);
     CK(hipMemcpy(hd.data(), dst, dframe, hipMemcpyDeviceToHost));
     uint64_t cs = 0; for (size_t i = 0; i < dframe; i += 97) cs = cs*31 + hd[i];
+    typedef int (*trace_t)(unsigned long long*);
+    if (trace_t rd = (trace_t)dlsym(h, "gf_debug_read_wg_trace")) {        // tools build with -DGF_TRACE_WG: timeline of the last launch
+        std::vector<unsigned long long> t(8192*3);
+        if (rd(t.data()) == 0) {
+            unsigned long long t0 = ~0ull, t1 = 0; int n = 0;
+            for (int i = 0; i < 8192; i++) if (t[i*3+1]) { t0 = std::min(t0, t[i*3]); t1 = std::max(t1, t[i*3+1]); n++; }
+            printf("wg trace: %d workgroups, launch span %.1f us (100 MHz clock)\n", n, (t1 - t0)/100.0);
+            // busy workgroups over time, 40 bins
+            const int NB = 40; std::vector<double> busy(NB, 0.0);
+            const double span = (double)(t1 - t0), bw = span/NB;
+            for (int i = 0; i < 8192; i++) if (t[i*3+1]) {
+                const double a = (double)(t[i*3] - t0), b = (double)(t[i*3+1] - t0);
+                for (int j = 0; j < NB; j++) { const double lo = j*bw, hi = lo + bw; busy[j] += std::max(0.0, std::min(b, hi) - std::max(a, lo))/bw; }
+            }
+            printf("resident workgroups per bin of %.1f us:", bw/100.0);
+            for (int j = 0; j < NB; j++) printf(" %.0f", busy[j]);
+            printf("\n");
+            // lifetime statistics
+            std::vector<double> life; for (int i = 0; i < 8192; i++) if (t[i*3+1]) life.push_back((t[i*3+1] - t[i*3])/100.0);
+            std::sort(life.begin(), life.end());
+            printf("workgroup lifetime us: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f\n", life[0], life[life.size()/10], life[life.size()/2], life[life.size()*9/10], life.back());
+            // first start and last end per XCC
+            for (int x = 0; x < 8; x++) {
+                unsigned long long a = ~0ull, b = 0, lastst = 0; int c = 0;
+                for (int i = 0; i < 8192; i++) if (t[i*3+1] && (int)(t[i*3+2] >> 32 & 15) == x) { a = std::min(a, t[i*3]); b = std::max(b, t[i*3+1]); lastst = std::max(lastst, t[i*3]); c++; }
+                if (c) printf("  xcc %d: %d wgs, first start %.1f us, last start %.1f us, last end %.1f us\n", x, c, (a - t0)/100.0, (lastst - t0)/100.0, (b - t0)/100.0);
+            }
+        }
+    }
     printf("%dx%d->%dx%d depth=%d border=%d frames=%d blend=%d: median %.3f ms (min %.3f) = %.2f us/frame, %.0f frames/s, %.0f GB/s algorithmic (%.1f%% of 8 TB/s) checksum %016llx\n",
            iw, ih, ow, oh, depth, border, frames, blend, med, mn, 1e3*med/frames, frames/(med*1e-3), bytes/(med*1e-3)/1e9,
            100*bytes/(med*1e-3)/8e12, (unsigned long long)cs);
