@@ -1,0 +1,33 @@
+"""CPU tests of bench.py's bookkeeping (no GPU): the algorithmic byte counts of SURVEY.md 8(d) and the touched-footprint figure."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_algorithmic_bytes_match_survey():
+    import bench
+    # C1 12.44 MB, C2 22.67 MB, C3 49.77 MB, C4 98.21 MB (two-pass), C5 input + output of one u16 frame
+    assert bench.algorithmic_bytes_per_frame("c1") == 6220800 + 6220800
+    assert bench.algorithmic_bytes_per_frame("c2") == 16451136 + 6220800
+    assert bench.algorithmic_bytes_per_frame("c3") == 24883200 * 2
+    assert bench.algorithmic_bytes_per_frame("c4") == 36000000 + 2 * 18662400 + 24883200
+    assert bench.algorithmic_bytes_per_frame("c5") == 2 * 95233536
+
+
+def test_touched_footprint_is_bounded_and_sensible(orc):
+    """Unique source bytes under the taps: never more than the frame, and for C2 (2704x2028 -> 1920x1080, fov 1) between a fifth and all of it."""
+    import bench
+    from gyroflow_amd import FisheyeCalibrator
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(os.path.join(ROOT, "tests", "golden", "presets", "hero8_27k_43.json"))
+    q = bench.load_quats()
+    t = bench.touched_source_bytes("c2", cal, q, [0, 500])
+    full = 2704 * 2028 * 3
+    assert 0.2 * full < t <= full          # measured: 29 % -- the 1080p output at fov 1 sees the middle of the 2.7K frame only
+    # identity rotation, same call: the footprint is symmetric about the frame centre, so it cannot exceed the frame either
+    t0 = bench.touched_source_bytes("c2", cal, np.array([[1.0, 0, 0, 0]]), [0])
+    assert 0.2 * full < t0 <= full
