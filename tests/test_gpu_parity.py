@@ -363,6 +363,47 @@ def test_error_codes(gpu):
         cv.remap(torch.zeros((4, 4, 3), dtype=torch.float32, device=gpu), m1[:4, :4], m2[:4, :4], cv.INTER_LINEAR)
 
 
+def test_fused_entry_error_codes(gpu):
+    """gf_undistort_rotate_c3 / _blend_c3 reject empty batches, missing transforms, short strides, overlapping buffers and bad
+    blend groups on the host, with a code and a message, before any launch."""
+    import ctypes as C
+    from gyroflow_amd import _lib
+    lib, ctx = _lib.load(), _lib.ctx(0)
+    w, h = 64, 48
+    src = torch.zeros((2, h, w, 3), dtype=torch.uint8, device=gpu)
+    dst = torch.zeros((2, h, w, 3), dtype=torch.uint8, device=gpu)
+    K = np.array([[50.0, 0, 32], [0, 50.0, 24], [0, 0, 1]])
+    one = _lib.xform_to_array(_lib.make_frame_xform(K, np.eye(3), K))
+    xf = torch.from_numpy(np.stack([one, one])).to(gpu)
+    D = _lib.distortion([0.01, 0, 0, 0]); bv = _lib.border_value(0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    fs = h * w * 3
+
+    def call(n=2, s=src, d=dst, x=xf, sstep=w * 3, sframe=fs, dstep=w * 3, dframe=fs, depth=0, border=0, ctx_=ctx):
+        return lib.gf_undistort_rotate_c3(ctx_, depth, p(s), w, h, sstep, sframe, p(d), w, h, dstep, dframe, D,
+                                          p(x) if x is not None else None, n, border, bv, None)
+
+    assert call(n=0) == -1 and b"frame count" in lib.gf_last_error()            # empty batch
+    assert call(n=70000) == -1
+    assert call(x=None) == -1 and b"xf_dev" in lib.gf_last_error()
+    assert call(sframe=fs - 1) == -1 and b"src_frame_stride" in lib.gf_last_error()
+    assert call(dframe=fs - 1) == -1 and b"dst_frame_stride" in lib.gf_last_error()
+    assert call(sstep=w * 3 - 1) == -1                                           # row step shorter than a row
+    assert call(d=src) == -1 and b"overlap" in lib.gf_last_error()
+    assert call(depth=1) == -3 and call(border=2) == -3                          # unsupported depth / border codes
+    assert call(ctx_=None) == -1
+    # sframe = 0 is allowed: every output frame reads the same source frame (OnlyUndistort); the launch itself must succeed
+    assert call(sframe=0) == 0
+    torch.cuda.synchronize()
+    # blend: n_blend must be in 1..frames_per_group, TRANSPARENT is refused
+    def blend(fpg, nb, border=0):
+        return lib.gf_undistort_rotate_blend_c3(ctx, 0, p(src), w, h, w * 3, fs, p(dst), w, h, w * 3, fs, D, p(xf), 1, fpg, nb, border, bv, None)
+    assert blend(2, 0) == -1 and blend(1, 2) == -1
+    assert blend(2, 2, border=5) == -3 and b"TRANSPARENT" in lib.gf_last_error()
+    assert blend(2, 2) == 0
+    torch.cuda.synchronize()
+
+
 def test_two_threads_two_streams_two_lenses(gpu, orc):
     """get_maps is called from the render thread and the preview thread on one calibrator (gyroflow.py:282):
     two Python threads, each on its own HIP stream and with its own lens (two slots of the context's lens cache), must
