@@ -131,6 +131,17 @@ int main(int argc, char** argv)
             std::vector<double> life; for (int i = 0; i < 8192; i++) if (t[i*3+1]) life.push_back((t[i*3+1] - t[i*3])/100.0);
             std::sort(life.begin(), life.end());
             printf("workgroup lifetime us: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f\n", life[0], life[life.size()/10], life[life.size()/2], life[life.size()*9/10], life.back());
+            // per compute unit (XCC, HW_ID bits 8..15 = CU, SH, SE): mean lifetime of the workgroups it ran -- systematic or random?
+            {
+                std::vector<double> sum(8*256, 0.0); std::vector<int> cnt(8*256, 0);
+                for (int i = 0; i < 8192; i++) if (t[i*3+1]) {
+                    const int key = (int)((t[i*3+2] >> 32) & 7)*256 + (int)((t[i*3+2] >> 8) & 255);
+                    sum[key] += (t[i*3+1] - t[i*3])/100.0; cnt[key]++;
+                }
+                std::vector<double> m; for (int q = 0; q < 8*256; q++) if (cnt[q]) m.push_back(sum[q]/cnt[q]);
+                std::sort(m.begin(), m.end());
+                if (!m.empty()) printf("per-CU mean lifetime us over %zu CUs: min %.1f  p10 %.1f  median %.1f  p90 %.1f  max %.1f\n", m.size(), m[0], m[m.size()/10], m[m.size()/2], m[m.size()*9/10], m.back());
+            }
             // first start and last end per XCC
             for (int x = 0; x < 8; x++) {
                 unsigned long long a = ~0ull, b = 0, lastst = 0; int c = 0;
