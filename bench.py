@@ -124,8 +124,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c3", choices=sorted(CONFIGS))
-    # 128 frames per launch: the fused kernel ends every launch with a ~120 us tail of partly idle CUs (workgroup lifetimes
-    # differ by +-25 %), so larger launches run closer to the steady-state rate; 2 x 3.2 GB of HBM at 4K
+    # 128 frames per launch: launch time fits 68 us + 19.1 us x frames (start-up and a tail of thinning workgroups, DESIGN.md
+    # section 3), so larger launches run closer to the steady-state rate; 2 x 3.2 GB of HBM at 4K
     ap.add_argument("--batch", type=int, default=128, help="frames per step (per GPU)")
     ap.add_argument("--cpu-frames", type=int, default=-1, help="frames in the CPU baseline sample (0 = skip)")
     ap.add_argument("--border", default="constant", choices=["constant", "replicate"])
