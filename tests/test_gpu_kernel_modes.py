@@ -43,7 +43,11 @@ def test_modes_4k_vs_oracle(gpu, orc, golden_calls, mode):
     got = got.reshape(2160, 3840, 3)
     assert torch.equal(got, cv.remap(src, g1, g2, cv.INTER_LINEAR))
     want = orc.remap_linear(frame, o1, o2, nthreads=8)
-    assert int((got.cpu().numpy() != want).sum()) <= 24
+    pd = np.abs(got.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+    print("C3 %s: %d map entries differ by one Q5 step; %d pixel values differ, max |diff| = %d LSB" % (mode, int((diff != 0).sum()), int((pd != 0).sum()), int(pd.max())))
+    assert int((pd != 0).sum()) <= 24
+    # a one-step Q5 flip moves a pixel by at most 1/32 of the local contrast: <= 8 LSB for u8
+    assert int(pd.max()) <= 8
 
 
 @pytest.mark.parametrize("border", [0, 1, 5])
