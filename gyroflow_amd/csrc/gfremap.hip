@@ -2346,7 +2346,10 @@ static int fused_checks(const char* fn, void* ctx, int depth, const void* src, i
     return GF_OK;
 }
 
-static int launch_fused(Ctx* c, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+// What launch_fused needs from a context (the allocation-free entry point has no Ctx: its tables live in `scratch`).
+struct FusedEnv { int k1_mode; int n_cu; const double* rp_tab; };
+
+static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                         void* dst, int dw, int dh, size_t dstep, size_t dframe, const double* lens, LensK lk,
                         const gf_frame_xform* xf_dev, int n_frames, int border, const double* bv, hipStream_t stream)
 {
@@ -2408,7 +2411,104 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     DeviceGuard dg(c->device);
     const double* lens; LensK lk;
     rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
-    return launch_fused(c, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
+    const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
+    return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
+                        border, bv, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// gf_undistort_rotate_c3_noalloc: gf_undistort_rotate_c3 for callers that cannot allocate (HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc).  It needs no context: the device memory the fused kernel uses beyond its inputs and
+// outputs -- the lens table, the RP table and the per-frame transforms -- lives in `scratch`, a static device array that
+// every GPU the library runs on holds until the process ends.  The tables are built on the host exactly as get_lens() /
+// gf_ctx_create() build them and reach the device as kernel arguments (k_scratch_put: 2 KB per launch), so the call makes
+// no hipMalloc / hipFree / hipMemcpy and queues nothing but kernels on the caller's stream.
+// `scratch` is a host-side stand-in in host code, not a device address: hipGetSymbolAddress gives the address, once per
+// device, and only that pointer is handed to kernels.
+constexpr int NOALLOC_MAX_FRAMES = GF_NOALLOC_MAX_FRAMES;
+struct NoAllocScratch {
+    double lens[LENS_DOUBLES];                 // 16 KB
+    double rp[RP_TAB_DOUBLES];                 // 4.6 KB
+    double xf[NOALLOC_MAX_FRAMES][13];         // 6.5 KB
+};
+static_assert(sizeof(Xf) == 13*sizeof(double) && offsetof(NoAllocScratch, rp) % 16 == 0 && offsetof(NoAllocScratch, xf) % 8 == 0, "scratch layout");
+}  // extern "C"
+
+static __device__ __align__(256) unsigned char scratch[sizeof(NoAllocScratch)];
+
+namespace {
+constexpr int PUT_DOUBLES = 256;               // doubles per k_scratch_put launch (2 KB of kernel arguments)
+struct PutChunk { double v[PUT_DOUBLES]; };
+__global__ void __launch_bounds__(PUT_DOUBLES) k_scratch_put(double* dst, PutChunk c, int n)
+{
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = c.v[threadIdx.x];
+}
+
+int scratch_put(double* dst_dev, const double* src_host, int n, hipStream_t stream)
+{
+    for (int o = 0; o < n; o += PUT_DOUBLES) {
+        PutChunk c;
+        const int m = n - o < PUT_DOUBLES ? n - o : PUT_DOUBLES;
+        memcpy(c.v, src_host + o, (size_t)m*sizeof(double));
+        if (m < PUT_DOUBLES) memset(c.v + m, 0, (size_t)(PUT_DOUBLES - m)*sizeof(double));
+        hipLaunchKernelGGL(k_scratch_put, dim3(1), dim3(PUT_DOUBLES), 0, stream, dst_dev + o, c, m);
+    }
+    HIP_TRY(hipGetLastError());
+    return GF_OK;
+}
+
+constexpr int NOALLOC_MAX_DEVICES = 64;
+struct NoAllocDev { NoAllocScratch* ptr; int n_cu; };    // ptr: this device's copy of `scratch` (each GPU has its own, at its own address)
+NoAllocDev g_noalloc[NOALLOC_MAX_DEVICES];
+std::mutex g_noalloc_mu;
+}  // namespace
+
+extern "C" {
+
+GF_API int gf_undistort_rotate_c3_noalloc(int device, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                                          void* dst, int dw, int dh, size_t dstep, size_t dframe,
+                                          const double D[4], const gf_frame_xform* xf_host, int n_frames, int border, const double bv[4],
+                                          gf_stream_t stream)
+{
+    static int dummy_ctx;      // fused_checks only tests the context pointer for NULL
+    int rc = fused_checks("gf_undistort_rotate_c3_noalloc", &dummy_ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_host, n_frames, n_frames, border);
+    if (rc) return rc;
+    if (n_frames > NOALLOC_MAX_FRAMES)
+        return fail(GF_ERR_INVALID_ARG, "gf_undistort_rotate_c3_noalloc: %s%lld frames exceed GF_NOALLOC_MAX_FRAMES (64); split the batch or use gf_undistort_rotate_c3", "", n_frames);
+    if (device < 0 || device >= NOALLOC_MAX_DEVICES) return fail(GF_ERR_INVALID_ARG, "gf_undistort_rotate_c3_noalloc: device %s%lld out of range", "", device);
+    if (!D) return fail(GF_ERR_INVALID_ARG, "%s: null distortion coefficients", "gf_undistort_rotate_c3_noalloc");
+    LensK lk;
+    for (int i = 0; i < 4; i++) {
+        if (!(D[i] == D[i]) || fabs(D[i]) > 1e6) return fail(GF_ERR_INVALID_ARG, "lens: distortion coefficient %s%lld is not finite", "", i);
+        lk.k[i] = D[i];
+    }
+    {   // as get_lens()
+        const double tm = atan(sqrt((double)((1 << LENS_OCT) - 1))), t2 = tm*tm;
+        lk.bound = tm*(1 + t2*(fabs(D[0]) + t2*(fabs(D[1]) + t2*(fabs(D[2]) + t2*fabs(D[3])))));
+    }
+    DeviceGuard dg(device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "gf_undistort_rotate_c3_noalloc: cannot select device %s%lld", "", device);
+    std::lock_guard<std::mutex> g(g_noalloc_mu);
+    NoAllocDev& nd = g_noalloc[device];
+    if (!nd.ptr) {             // first call on this device, with the device current: resolve its copy of the symbol
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        int n_cu = 0;
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || n_cu <= 0) n_cu = 256;
+        nd.n_cu = n_cu;
+        nd.ptr = (NoAllocScratch*)p;
+    }
+    NoAllocScratch* S = nd.ptr;
+    // Every call rewrites what it uses (the array keeps the last call's contents, and a captured graph must be
+    // self-contained): lens table, RP table, this call's transforms.  Stream order puts them before the fused kernel.
+    static thread_local double host_tab[LENS_DOUBLES > RP_TAB_DOUBLES ? LENS_DOUBLES : RP_TAB_DOUBLES];
+    build_lens_table(D, host_tab);
+    rc = scratch_put(S->lens, host_tab, LENS_DOUBLES, (hipStream_t)stream); if (rc) return rc;
+    build_rp_table(host_tab);
+    rc = scratch_put(S->rp, host_tab, RP_TAB_DOUBLES, (hipStream_t)stream); if (rc) return rc;
+    rc = scratch_put(&S->xf[0][0], (const double*)xf_host, n_frames*13, (hipStream_t)stream); if (rc) return rc;
+    const FusedEnv env{g_k1_mode == GF_KERNEL_DIRECT ? GF_KERNEL_DIRECT : GF_KERNEL_RP, nd.n_cu, S->rp};
+    return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, S->lens, lk, (const gf_frame_xform*)&S->xf[0][0], n_frames,
                         border, bv, (hipStream_t)stream);
 }
 

@@ -145,6 +145,21 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
                            const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
                            int border, const double border_value_host[4], gf_stream_t stream);
 
+/* gf_undistort_rotate_c3 for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  (No counterpart in the reference.)  Same arithmetic, same kernels and bit-identical output, but no
+ * context: the device memory the kernel needs beyond src and dst (lens table, RP table, the batch's transforms: 28 KB)
+ * lives in a static device array inside the library, which every GPU the library runs on holds until the process ends.
+ * The call allocates and frees nothing, copies nothing with hipMemcpy and never synchronises: the tables and xf_host (a
+ * HOST array of n_frames transforms, read before the call returns) reach the device as kernel arguments of small
+ * launches queued on `stream` ahead of the fused kernel.  n_frames <= GF_NOALLOC_MAX_FRAMES, else GF_ERR_INVALID_ARG.
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race;
+ * calls queued on one stream do not.  Kernel variant: RP (DIRECT if the process runs with GF_K1=direct). */
+#define GF_NOALLOC_MAX_FRAMES 64
+GF_API int gf_undistort_rotate_c3_noalloc(int device, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                                   void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                                   const double D_host[4], const gf_frame_xform* xf_host, int n_frames,
+                                   int border, const double border_value_host[4], gf_stream_t stream);
+
 /* Hyperlapse blend, replaces the numpy float64 passes at stabilizer.py:1434 (reset), :1447 (accumulate)
  * and :1468 (truncating cast).  acc is double [n] with n = w*h*3. */
 GF_API int gf_blend_accumulate(void* ctx, int depth, const void* frame, double* acc, double weight, int reset,
