@@ -926,7 +926,7 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
 // and k_fisheye_maps_rp use the same functions on the same tile grid, so their coordinates are identical bit for bit.
 static_assert(RP_N == 8 && RT == 64 && BLOCK == 256, "lane <-> node and thread <-> row mappings below");
 #ifndef GF_RP_WAVES
-#define GF_RP_WAVES 2
+#define GF_RP_WAVES 4            /* waves per SIMD the RP kernel is compiled for: keeps it within 128 VGPRs */
 #endif
 
 struct RpConst {                    // LDS copies of build_rp_table's constants
@@ -1019,10 +1019,37 @@ __device__ __forceinline__ void rp_rows(const double (*C2)[RP_N], const RpConst&
     }
 }
 
+// Frame / row constants of the RP coordinates.  32u = fx32 (j ax + (i iR1 + iR2)) G + cx32 is evaluated as
+// fma(fma(j, ax', rx'), G, cx32) with ax' = ax fx32 and rx' = fma(i, iR1 fx32, iR2 fx32): the focal length is folded into the
+// ray once per frame (RpFrameC) and once per row (RpRowC), which leaves 3 f64 operations per coordinate and pixel.  Every
+// RP kernel (fused, LDS-box, maps, blend) goes through these functions, so their coordinates agree bit for bit.
+struct RpFrameC { double axp, ayp, b1x, b2x, b1y, b2y, cx32, cy32; };
+struct RpRowC { double axp, ayp, rxp, ryp, cx32, cy32; };
+
+__device__ __forceinline__ RpFrameC rp_frame_consts(const Xf& xf)
+{
+    RpFrameC t;
+    const double fx32 = xf.f[0]*32.0, fy32 = xf.f[1]*32.0;       // exact scalings
+    t.axp = xf.iR[0]*fx32; t.b1x = xf.iR[1]*fx32; t.b2x = xf.iR[2]*fx32;
+    t.ayp = xf.iR[3]*fy32; t.b1y = xf.iR[4]*fy32; t.b2y = xf.iR[5]*fy32;
+    t.cx32 = xf.c[0]*32.0; t.cy32 = xf.c[1]*32.0;
+    return t;
+}
+
+__device__ __forceinline__ RpRowC rp_row_consts(const RpFrameC& t, int i)
+{
+    RpRowC r;
+    const double di = (double)i;
+    r.axp = t.axp; r.ayp = t.ayp; r.cx32 = t.cx32; r.cy32 = t.cy32;
+    r.rxp = __fma_rn(di, t.b1x, t.b2x);
+    r.ryp = __fma_rn(di, t.b1y, t.b2y);
+    return r;
+}
+
 // Q5 integers of the thread's PXT pixels (columns x0 .. x0 + 3 of the row with constants rc) from the row's coefficients:
 // low dwords of 32u + mu and 32v + mv.  mu = mv = ROUND_MAGIC gives rint(32u), rint(32v); ROUND_MAGIC - 32 k (k an integer)
 // gives them relative to source position k with the same ties (the offset is even).
-__device__ __forceinline__ void rp_coords(const RowC& rc, const double* crow, const double* z, int x0, double mu, double mv, int* iu, int* iv)
+__device__ __forceinline__ void rp_coords(const RpRowC& rc, const double* crow, const double* z, int x0, double mu, double mv, int* iu, int* iv)
 {
     static_assert(RP_N == 8, "Horner chain is written for degree 7");
     const double2* c = (const double2*)crow;
@@ -1033,10 +1060,31 @@ __device__ __forceinline__ void rp_coords(const RowC& rc, const double* crow, co
         G = __fma_rn(G, z[e], c2.y); G = __fma_rn(G, z[e], c2.x); G = __fma_rn(G, z[e], c1.y); G = __fma_rn(G, z[e], c1.x);
         G = __fma_rn(G, z[e], c0.y); G = __fma_rn(G, z[e], c0.x);
         const double dj = (double)(x0 + e);
-        const double X = __fma_rn(dj, rc.ax, rc.rx), Y = __fma_rn(dj, rc.ay, rc.ry);
-        iu[e] = __double2loint(__fma_rn(X*G, rc.fx32, rc.cx32) + mu);
-        iv[e] = __double2loint(__fma_rn(Y*G, rc.fy32, rc.cy32) + mv);
+        const double X = __fma_rn(dj, rc.axp, rc.rxp), Y = __fma_rn(dj, rc.ayp, rc.ryp);
+        iu[e] = __double2loint(__fma_rn(X, G, rc.cx32) + mu);
+        iv[e] = __double2loint(__fma_rn(Y, G, rc.cy32) + mv);
     }
+}
+
+// The per-pixel fallback of the RP kernels as a call: tiles that fail rp_nodes' checks are rare, and inlined this code costs
+// the hot loop about 30 VGPRs.  Results come back in registers.
+struct Q5x4 { int iu[PXT], iv[PXT]; };
+__device__ __noinline__ Q5x4 coord_q5x4_cold(const Xf* xfp, double k0, double k1, double k2, double k3, double bound, const double2* tab, int y, int x0)
+{
+    const Xf xf = *xfp;
+    LensK lk; lk.k[0] = k0; lk.k[1] = k1; lk.k[2] = k2; lk.k[3] = k3; lk.bound = bound;
+    Q5x4 q = {};
+    const RowC rc = row_consts(xf, y);
+    const unsigned hi_limit = lens_hi_limit(xf, lk);
+#pragma unroll 1
+    for (int e = 0; e < PXT; e++) {                      // one pixel at a time: few live registers (same arithmetic as coord_q5x4)
+        int u, v;
+        coord_q5(rc, xf, lk, hi_limit, tab, x0 + e, u, v);
+        // q.iu[e] with a dynamic e would go through memory: select into the four registers instead
+        q.iu[0] = e == 0 ? u : q.iu[0]; q.iu[1] = e == 1 ? u : q.iu[1]; q.iu[2] = e == 2 ? u : q.iu[2]; q.iu[3] = e == 3 ? u : q.iu[3];
+        q.iv[0] = e == 0 ? v : q.iv[0]; q.iv[1] = e == 1 ? v : q.iv[1]; q.iv[2] = e == 2 ? v : q.iv[2]; q.iv[3] = e == 3 ? v : q.iv[3];
+    }
+    return q;
 }
 
 // The tile's source box (wave-uniform): tap positions bx0 .. bx1, by0 .. by1 (with their right and lower neighbours) are held
@@ -1176,14 +1224,22 @@ __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(Rema
             const bool ok = S.ok[k & 3] != 0;
             const int cb = (int)(k & 1);
             if (x0 < A.dw) {
+                const RpFrameC fc = rp_frame_consts(xf);
 #pragma unroll 1
                 for (int pass = 0; pass < RT_NPASS; pass++) {
                     const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
                     if (y >= A.dh) break;
-                    const RowC rc = row_consts(xf, y);
                     int iu[PXT], iv[PXT], px[PXT][3];
-                    if (ok) rp_coords(rc, S.C[cb][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
-                    else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+                    if (ok) rp_coords(rp_row_consts(fc, y), S.C[cb][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+#ifdef GF_RP_COLD_CALL
+                    else {
+                        const Q5x4 q = coord_q5x4_cold(&xf, lk.k[0], lk.k[1], lk.k[2], lk.k[3], lk.bound, s_tab, y, x0);
+#pragma unroll
+                        for (int e = 0; e < PXT; e++) { iu[e] = q.iu[e]; iv[e] = q.iv[e]; }
+                    }
+#else
+                    else coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+#endif
                     const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
                     uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
                     store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
@@ -1301,12 +1357,11 @@ __global__ void __launch_bounds__(BLOCK_RL, (GF_RL_WGS*(BLOCK_RL/64) + 3)/4) k_u
                 for (int pass = 0; pass < RT_NPASS; pass++) {
                     const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
                     if (y >= A.dh) break;
-                    const RowC rc = row_consts(xf, y);
                     int iu[PXT], iv[PXT], px[PXT][3];
                     unsigned keep = 0;
                     bool done = false;
                     if (ok) {
-                        rp_coords(rc, S.C[cb][rr], z, x0, mu, mv, iu, iv);
+                        rp_coords(rp_row_consts(rp_frame_consts(xf), y), S.C[cb][rr], z, x0, mu, mv, iu, iv);
                         const unsigned rumax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
                         const unsigned rvmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
                         if (rumax < B.NXq && rvmax < B.NYq) {
@@ -1318,7 +1373,7 @@ __global__ void __launch_bounds__(BLOCK_RL, (GF_RL_WGS*(BLOCK_RL/64) + 3)/4) k_u
                             for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
                         }
                     } else {
-                        coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), (const double2*)lens, x0, iu, iv);
+                        coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), (const double2*)lens, x0, iu, iv);
                     }
                     if (!done) keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
                     uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
@@ -1356,10 +1411,9 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, cons
     for (int pass = 0; pass < RT_NPASS; pass++) {
         const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
         if (y >= h) break;
-        const RowC rc = row_consts(xf, y);
         int iu[PXT], iv[PXT];
-        if (ok) rp_coords(rc, S.C[0][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
-        else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+        if (ok) rp_coords(rp_row_consts(rp_frame_consts(xf), y), S.C[0][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+        else coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
         int16_t* m1 = (int16_t*)(map1 + (size_t)y*m1step);
         uint16_t* m2 = (uint16_t*)(map2 + (size_t)y*m2step);
 #pragma unroll
@@ -1499,10 +1553,9 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A
             const int frame = g*frames_per_group + b;
             const Xf& xf = xfs[frame];
             const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
-            const RowC rc = row_consts(xf, y);
             int iu[PXT], iv[PXT], o[PXT][3];
-            if (okf[b]) rp_coords(rc, C[b][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
-            else coord_q5x4(rc, xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
+            if (okf[b]) rp_coords(rp_row_consts(rp_frame_consts(xf), y), C[b][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+            else coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
             remap4<DEPTH, BORDER>(s, iu, iv, A.cval, o);
 #pragma unroll
             for (int i = 0; i < PXT; i++)
