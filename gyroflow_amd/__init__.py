@@ -9,10 +9,10 @@ from .adaptive_zoom import AdaptiveZoom                  # noqa: F401
 from .calibrate_video import FisheyeCalibrator           # noqa: F401
 from .nonlinear_stretch import NonlinearStretch          # noqa: F401
 from .stabilizer import Stabilizer, OnlyUndistort, ArraySource, ListSink, NullSink, synthetic_frames   # noqa: F401
-from .frameio import RawVideoSource, RawVideoSink         # noqa: F401
+from .frameio import RawVideoSource, RawVideoSink, PinnedRingSource         # noqa: F401
 from .gyro_integrator import GyroIntegrator              # noqa: F401
 from .smoothing_algos import PlainSlerp                  # noqa: F401
 
 __all__ = ["cv", "FisheyeCalibrator", "AdaptiveZoom", "NonlinearStretch", "Stabilizer", "OnlyUndistort", "ArraySource", "ListSink", "NullSink",
-           "RawVideoSource", "RawVideoSink", "GyroIntegrator", "PlainSlerp",
+           "RawVideoSource", "RawVideoSink", "PinnedRingSource", "GyroIntegrator", "PlainSlerp",
            "synthetic_frames"]

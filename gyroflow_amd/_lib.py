@@ -40,6 +40,7 @@ SIGNATURES = {
     "gf_ctx_destroy": [_vp],
     "gf_ctx_set_kernel_mode": [_vp, _i],
     "gf_make_frame_xform": [_dp, _dp, _dp, C.POINTER(FrameXform)],
+    "gf_make_frame_xforms": [_dp, _dp, _dp, _sz, _vp],
     "gf_fisheye_maps_16sc2": [_vp, _dp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
     "gf_fisheye_maps_32f": [_vp, _dp, C.POINTER(FrameXform), _i, _i, _vp, _sz, _vp, _sz, _vp],
     "gf_convert_maps_32f_16sc2": [_vp, _vp, _sz, _vp, _sz, _f, _f, _f, _f, _i, _i, _vp, _sz, _vp, _sz, _vp],
@@ -137,6 +138,20 @@ def make_frame_xform(K, R, P):
     Pc = np.ascontiguousarray(np.asarray(P, np.float64)[:, :3].reshape(9))
     out = FrameXform()
     check(lib.gf_make_frame_xform(Kc.ctypes.data_as(_dp), Rc.ctypes.data_as(_dp), Pc.ctypes.data_as(_dp), C.byref(out)))
+    return out
+
+
+def make_frame_xforms(K, Rs, Ps):
+    """Host: one lens matrix K, n rotations [n,3,3] and n new camera matrices [n,3,3] -> [n,13] float64 (rows = FrameXform)."""
+    lib = load()
+    Kc = np.ascontiguousarray(np.asarray(K, np.float64).reshape(9))
+    Rc = np.ascontiguousarray(np.asarray(Rs, np.float64).reshape(-1, 9))
+    Pc = np.ascontiguousarray(np.asarray(Ps, np.float64).reshape(-1, 9))
+    if Rc.shape != Pc.shape:
+        raise ValueError("Rs and Ps must hold the same number of 3x3 matrices")
+    out = np.empty((Rc.shape[0], XFORM_DOUBLES), np.float64)
+    check(lib.gf_make_frame_xforms(Kc.ctypes.data_as(_dp), Rc.ctypes.data_as(_dp), Pc.ctypes.data_as(_dp), Rc.shape[0],
+                                   out.ctypes.data_as(_vp)))
     return out
 
 

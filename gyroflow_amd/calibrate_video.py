@@ -191,12 +191,28 @@ class FisheyeCalibrator:
         return _lib.xform_to_array(_lib.make_frame_xform(scaled_K, R, new_K))
 
     def frame_xforms(self, fov_scales, quats, output_dim=None, new_img_dim=None, focalCenters=None):
-        """[N,13] float64: frame_xform() for every (fov_scale[i], quat[i], focalCenter[i])."""
-        quats = np.asarray(quats, np.float64)
+        """[N,13] float64: frame_xform() for every (fov_scale[i], quat[i], focalCenter[i]), built in one pass: the same float64
+        operations as _frame_matrices (calibrate_video.py:351-370), element-wise over the batch, then one C call."""
+        if self.image_is_stretched():
+            raise NotImplementedError("stretched presets go through get_maps() + remap() (float32 map rescale)")
+        quats = np.asarray(quats, np.float64).reshape(-1, 4)
         n = quats.shape[0]
-        fov_scales = np.broadcast_to(np.asarray(fov_scales, np.float64), (n,))
-        out = np.empty((n, _lib.XFORM_DOUBLES), np.float64)
-        for i in range(n):
-            fc = None if focalCenters is None else focalCenters[i]
-            out[i] = self.frame_xform(float(fov_scales[i]), output_dim, new_img_dim, quats[i], fc)
-        return out
+        fov = np.broadcast_to(np.asarray(fov_scales, np.float64), (n,))
+        img_dim = new_img_dim if new_img_dim else self.calib_dimension
+        out_dim = output_dim if output_dim else self.calib_dimension
+        cd = self.calib_dimension
+        if focalCenters is None:
+            fc = np.broadcast_to(np.array([cd[0] / 2, cd[1] / 2]), (n, 2))
+        else:
+            fc = np.asarray(focalCenters, np.float64).reshape(n, 2)
+        R = Rotation.from_quat(quats[:, [1, 2, 3, 0]]).as_matrix()
+        R[:, [0, 0, 1, 2], [1, 2, 0, 0]] *= -1
+        img_dim_ratio = img_dim[0] / cd[0]
+        scaled_K = self.K * img_dim_ratio
+        scaled_K[2][2] = 1.0
+        P = np.tile(np.asarray(self.K, np.float64), (n, 1, 1))
+        P[:, 0, 0] = P[:, 0, 0] * 1.0 / fov
+        P[:, 1, 1] = P[:, 1, 1] * 1.0 / fov
+        P[:, 0, 2] = (cd[0] / 2 - fc[:, 0]) * img_dim_ratio / fov + out_dim[0] / 2
+        P[:, 1, 2] = (cd[1] / 2 - fc[:, 1]) * img_dim_ratio / fov + out_dim[1] / 2
+        return _lib.make_frame_xforms(scaled_K, R, P)

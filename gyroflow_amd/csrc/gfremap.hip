@@ -2259,6 +2259,16 @@ GF_API int gf_make_frame_xform(const double K[9], const double R[9], const doubl
     return GF_OK;
 }
 
+GF_API int gf_make_frame_xforms(const double K[9], const double* R, const double* P, size_t n, gf_frame_xform* out)
+{
+    if (!K || !R || !P || !out) return fail(GF_ERR_INVALID_ARG, "%s: null pointer", "gf_make_frame_xforms");
+    for (size_t i = 0; i < n; i++) {
+        const int rc = gf_make_frame_xform(K, R + 9*i, P + 9*i, out + i);
+        if (rc) return fail(rc, "gf_make_frame_xforms: %s (frame %lld)", "P*R is singular", (long long)i);
+    }
+    return GF_OK;
+}
+
 static int maps_common(void* ctx, const double* D, const gf_frame_xform* xf, int w, int h, void* m1, size_t s1, void* m2, size_t s2,
                        bool fixed, gf_stream_t stream)
 {

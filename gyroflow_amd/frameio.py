@@ -46,6 +46,31 @@ class RawVideoSource:
         del self._mm
 
 
+class PinnedRingSource:
+    """`count` frames cycling over a ring of frames held in pinned host memory: read() hands out pinned torch tensors, which
+    BatchPipeline uploads from where they lie (no staging copy).  Stands in for a decoder that writes into its own pinned
+    output ring; the ring is never rewritten, so a frame stays valid while its upload is in flight."""
+
+    def __init__(self, frames, count):
+        import torch
+        self._ring = torch.from_numpy(np.ascontiguousarray(np.stack(frames))).pin_memory()
+        self.count = int(count)
+        self.pos = 0
+
+    def get_pos(self):
+        return self.pos
+
+    def set_pos(self, n):
+        self.pos = int(n)
+
+    def read(self):
+        if self.pos >= self.count:
+            return False, None
+        f = self._ring[self.pos % self._ring.shape[0]]
+        self.pos += 1
+        return True, f
+
+
 class RawVideoSink:
     """Appends frames to a headerless raw-video file: write(frame)/close() like vidgear's WriteGear."""
 

@@ -1,12 +1,17 @@
-"""Pinned, double-buffered frame streaming (SURVEY.md kernel row K7).
+"""Pinned, multi-buffered frame streaming (SURVEY.md kernel row K7).
 
 The reference moves one frame in and one frame out of its loop per iteration through host memory
 (/root/reference/stabilizer.py:1383 cap.read(), :1487 out.write()).  Here a batch of frames is staged in pinned
 host memory, uploaded with hipMemcpyAsync on a copy stream, processed on a compute stream and downloaded on a
 third stream, with `depth` slots in flight so PCIe transfers overlap the kernels.
+
+Every slot owns all the memory a batch touches on either side of the bus -- frames in, frames out and the batch's
+per-frame transforms -- so nothing a queued kernel reads can be recycled before the slot is retired.
 """
 import numpy as np
 import torch
+
+from . import _lib
 
 
 def _np_dtype(dt):
@@ -14,13 +19,16 @@ def _np_dtype(dt):
 
 
 class BatchPipeline:
-    """depth-slot ring of (pinned in, device in, device out, pinned out) batch buffers on three HIP streams.
+    """depth-slot ring of (pinned in, device in, device out, pinned out, transforms) batch buffers on three HIP streams.
 
-    submit(frames, launch) stages `frames` (list of HxWx3 numpy arrays, len <= batch; or an already pinned
-    [n,H,W,3] torch tensor, e.g. a decoder's own output ring, which is uploaded without the staging copy) and enqueues
-    upload -> launch(dev_in[:n], dev_out[:m]) -> download.  `launch` runs with the compute stream current and returns
-    m, the number of output frames it wrote into dev_out.  Finished batches are handed, in submission order, to
-    `deliver(out_frames_numpy_view)`; the view is only valid during the call."""
+    Per batch:  slot = acquire()  ->  stage(slot, i, frame) for every frame  ->  commit(slot, n, launch, xf).
+    stage() accepts a numpy frame (copied into the slot's pinned buffer: the one host copy a decoder's output costs) or a
+    pinned torch tensor (uploaded straight from where it lies, e.g. a decoder's own pinned ring); either way the upload of
+    frame i is queued at once, so it overlaps the staging of frame i + 1.  commit() uploads the [n,13] transforms `xf` into
+    the slot's own device buffer and queues launch(dev_in[:n], dev_out, dev_xf[:n]) -> download.  `launch` runs with the
+    compute stream current and returns m, the number of output frames it wrote into dev_out.  Finished batches are handed,
+    in submission order, to `deliver(out_frames_numpy_view)`; the view is only valid during the call.
+    submit(frames, launch, xf) does the three steps for a list of frames or one pinned [n,H,W,3] tensor."""
 
     def __init__(self, device, in_shape, out_shape, dtype, batch, deliver, depth=2, out_batch=None):
         self.dev = torch.device(device)
@@ -41,11 +49,17 @@ class BatchPipeline:
                     hout=torch.empty((self.out_batch, oh, ow, 3), dtype=dtype).pin_memory(),
                     din=torch.empty((self.batch, ih, iw, 3), dtype=dtype, device=self.dev),
                     dout=torch.zeros((self.out_batch, oh, ow, 3), dtype=dtype, device=self.dev),
+                    hxf=torch.zeros((self.batch, _lib.XFORM_DOUBLES), dtype=torch.float64).pin_memory(),
+                    dxf=torch.zeros((self.batch, _lib.XFORM_DOUBLES), dtype=torch.float64, device=self.dev),
                     ev_h2d=torch.cuda.Event(), ev_comp=torch.cuda.Event(), ev_d2h=torch.cuda.Event(),
                     pending=0, busy=False))
+            # the allocations above (zero fills included) ran on the current stream: finish them before any side stream
+            # touches the buffers
+            torch.cuda.current_stream(self.dev).synchronize()
         for s in self.slots:
             s["hin_np"] = s["hin"].numpy()
             s["hout_np"] = s["hout"].numpy()
+            s["hxf_np"] = s["hxf"].numpy()
         self.k = 0
 
     def _retire(self, slot):
@@ -53,41 +67,69 @@ class BatchPipeline:
             slot["ev_d2h"].synchronize()
             slot["busy"] = False
             if slot["pending"]:
-                self.deliver(slot["hout_np"][:slot["pending"]])
-                slot["pending"] = 0
+                m, slot["pending"] = slot["pending"], 0
+                self.deliver(slot["hout_np"][:m])
 
-    def submit(self, frames, launch):
+    def acquire(self):
+        """The next slot of the ring, with its previous batch fully downloaded and delivered."""
         slot = self.slots[self.k % self.depth]
         self.k += 1
-        self._retire(slot)                       # the slot's previous batch must be fully downloaded and delivered
-        n = len(frames)
-        if n == 0 or n > self.batch:
-            raise ValueError("batch of %d frames does not fit the pipeline's %d" % (n, self.batch))
-        if isinstance(frames, torch.Tensor):
-            if not frames.is_pinned():
-                raise ValueError("a tensor batch must live in pinned host memory")
-            hsrc = frames
+        self._retire(slot)
+        return slot
+
+    def stage(self, slot, i, frame):
+        """Frame i of the slot's batch: host -> pinned (unless it already is) -> device, queued on the upload stream."""
+        if i >= self.batch:
+            raise ValueError("frame %d does not fit the pipeline's batch of %d" % (i, self.batch))
+        if isinstance(frame, torch.Tensor):
+            if not frame.is_pinned():
+                raise ValueError("a tensor frame must live in pinned host memory")
+            hsrc = frame
         else:
-            for i, f in enumerate(frames):
-                slot["hin_np"][i] = f           # host copy into pinned memory (stands in for the decoder's output)
-            hsrc = slot["hin"][:n]
+            slot["hin_np"][i] = frame           # the decoder-output -> pinned copy
+            hsrc = slot["hin"][i]
+        with torch.cuda.device(self.dev), torch.cuda.stream(self.s_h2d):
+            slot["din"][i].copy_(hsrc, non_blocking=True)
+
+    def commit(self, slot, n, launch, xf=None):
+        if n <= 0 or n > self.batch:
+            raise ValueError("batch of %d frames does not fit the pipeline's %d" % (n, self.batch))
         with torch.cuda.device(self.dev):
             with torch.cuda.stream(self.s_h2d):
-                slot["din"][:n].copy_(hsrc, non_blocking=True)
+                dxf = None
+                if xf is not None:
+                    slot["hxf_np"][:n] = xf
+                    slot["dxf"][:n].copy_(slot["hxf"][:n], non_blocking=True)
+                    dxf = slot["dxf"][:n]
                 slot["ev_h2d"].record(self.s_h2d)
             with torch.cuda.stream(self.s_comp):
                 self.s_comp.wait_event(slot["ev_h2d"])
-                m = int(launch(slot["din"][:n], slot["dout"]))
+                m = int(launch(slot["din"][:n], slot["dout"], dxf))
                 slot["ev_comp"].record(self.s_comp)
             with torch.cuda.stream(self.s_d2h):
                 self.s_d2h.wait_event(slot["ev_comp"])
                 if m:
                     slot["hout"][:m].copy_(slot["dout"][:m], non_blocking=True)
                 slot["ev_d2h"].record(self.s_d2h)
-            # the next upload into this slot's din must not overtake this kernel; the next kernel writing dout
-            # must not overtake this download: both are ordered by _retire()'s host wait on ev_d2h.
+            # the next upload into this slot's din / dxf must not overtake this kernel; the next kernel writing dout
+            # must not overtake this download: both are ordered by acquire()'s host wait on ev_d2h.
         slot["pending"] = m
         slot["busy"] = True
+
+    def submit(self, frames, launch, xf=None):
+        slot = self.acquire()
+        n = len(frames)
+        if n == 0 or n > self.batch:
+            raise ValueError("batch of %d frames does not fit the pipeline's %d" % (n, self.batch))
+        if isinstance(frames, torch.Tensor):
+            if not frames.is_pinned():
+                raise ValueError("a tensor batch must live in pinned host memory")
+            with torch.cuda.device(self.dev), torch.cuda.stream(self.s_h2d):
+                slot["din"][:n].copy_(frames, non_blocking=True)
+        else:
+            for i, f in enumerate(frames):
+                self.stage(slot, i, f)
+        self.commit(slot, n, launch, xf)
 
     def flush(self):
         for j in range(self.depth):

@@ -263,13 +263,14 @@ class Stabilizer:
                                           quat=self.stab_transform[frame_num], focalCenter=focal)
 
     # ------------------------------------------------------------------ render loop
-    def schedule(self, first_pos, n_iter, first_iter=0):
+    def schedule(self, first_pos, n_iter, first_iter=0, with_iter=False):
         """The reference loop's control flow (stabilizer.py:1378-1411, 1431-1438, 1464) without any pixel work.
 
         Reads n_iter frames starting at source position first_pos and yields, for every successfully read frame,
         (frame_num, frame, phase, remap, emit): phase = (i-1) % hyperlapse_multiplier with i the reference's loop
-        counter, remap = the frame is inside the blended window, emit = an output frame is written after it.
-        Stops on exhausted stab_transform or after more than five consecutive failed reads.  Pure host logic."""
+        counter, remap = the frame is inside the blended window, emit = an output frame is written after it
+        (with_iter=True appends i-1 itself).  Stops on exhausted stab_transform or after more than five consecutive
+        failed reads.  Pure host logic."""
         mult, nblend = self.hyperlapse_multiplier, self.hyperlapse_num_blended_frames
         self.cap.set_pos(first_pos)
         num_not_success, num_not_success_lim = 0, 5
@@ -289,110 +290,236 @@ class Stabilizer:
             if not success:
                 continue
             phase = k % mult
-            yield frame_num, frame, phase, phase < nblend, (phase - nblend + 1) % mult == 0
+            ev = (frame_num, frame, phase, phase < nblend, (phase - nblend + 1) % mult == 0)
+            yield ev + (k,) if with_iter else ev
 
-    def renderfile(self, starttime, stoptime, sink, out_size=(1920, 1080), fov_scale=1.0, smoothingFocus=4.0,
-                   bg_color="#000000", batch=8, pipeline_depth=2, sequential=False, rank=0, world=1):
-        """Render [starttime, stoptime) through the fused undistort+rotate kernel into `sink`.
+    VALID_EXTENSIONS = ["webm", "flv", "vob", "ogv", "ogg", "drc", "gif", "mng", "avi", "mts", "m2ts", "ts", "mov", "qt", "yuv",
+                        "rmvb", "viv", "asf", "amv", "mp4", "m4p", "m4v", "mpg", "mpeg", "m2v", "svi", "3gp", "3g2", "mxf", "roq",
+                        "nsv", "flv"]
 
-        Returns the number of frames written.  `sequential=True` (always used for bg_color="HISTORY" and stretched
-        presets) issues the reference's per-frame sequence get_maps -> remap -> blend; otherwise frames are batched
-        through the pinned three-stream pipeline and the fused kernels.  With world > 1 this rank renders only its
-        contiguous shard of the loop iterations (frame_shard); concatenating the ranks' outputs in rank order gives
-        the single-GPU result."""
+    @staticmethod
+    def default_batch(frame_bytes):
+        """Frames per launch of the batched path: the fused kernel's launch cost is about 68 us + 19 us per 4K frame
+        (DESIGN.md K1), so launches of 64 4K frames (1.6 GB) run within 6 % of the steady rate; smaller frames get
+        proportionally more per launch, capped at 256."""
+        return int(min(256, max(8, (64 * 3840 * 2160 * 3) // max(int(frame_bytes), 1))))
+
+    def renderfile(self, starttime, stoptime, outpath="Stabilized.mp4", out_size=(1920, 1080), split_screen=False,
+                   bitrate_mbits=20, display_preview=False, scale=1, vcodec="libx264", vprofile="main", pix_fmt="",
+                   debug_text=False, custom_ffmpeg="", smoothingFocus=4.0, fov_scale=1.0, bg_color="#000000", audio=True,
+                   viewer_thread=None, *, batch=None, pipeline_depth=2, sequential=False, rank=0, world=1):
+        """Render [starttime, stoptime) through the fused undistort+rotate kernel (reference: stabilizer.py:1220-1531, same
+        positional and keyword arguments).  Returns the number of frames written (the reference returns None).
+
+        `outpath` is a frame sink (anything with write(frame) / close(): ListSink, NullSink, RawVideoSink, an encoder
+        pipe) or a path: encoding is out of scope here, so a path receives the frames as headerless raw video (what the
+        reference pipes into ffmpeg through WriteGear, :1326) after the reference's file-extension check (:1230-1233).  The
+        encoder options (bitrate_mbits, vcodec, vprofile, pix_fmt, custom_ffmpeg -- never eval'd --, audio) are accepted and
+        ignored; split_screen and scale are dead in the reference too (:1470, :1415) and ignored alike; debug_text draws
+        with cv2 and is not available: the call prints that and returns, like the reference's own early exits.  Nothing
+        raises out of the loop: a failed write prints and stops the render (:1486-1491).
+
+        Keyword-only extensions: `sequential=True` (always used for bg_color="HISTORY") issues the reference's per-frame
+        sequence get_maps -> remap -> blend; otherwise frames are batched (`batch` per launch, default by frame size)
+        through the pinned multi-stream pipeline and the fused kernels.  With world > 1 this rank renders only its
+        contiguous shard of the loop iterations (frame_shard); concatenating the ranks' outputs in rank order gives the
+        single-GPU result."""
+        if isinstance(outpath, str) and outpath.split(".")[-1].lower() not in self.VALID_EXTENSIONS:
+            print(f"{outpath} does not have a valid file extension")
+            return
+        if debug_text:
+            print("debug_text overlays are drawn with cv2.rectangle/cv2.putText in the reference: not available here")
+            return
         borderMode, borderValue = self.border_from_bg_color(bg_color)
+        if world > 1 and borderMode == cv.BORDER_TRANSPARENT:
+            print('bg_color="HISTORY" makes every frame depend on the previous output: it does not shard')
+            return
+        if (vcodec, vprofile, pix_fmt, custom_ffmpeg, bitrate_mbits, audio) != ("libx264", "main", "", "", 20, True):
+            print("Note: encoder options are ignored (frames go to the sink unencoded)")
+        if isinstance(outpath, str):
+            from .frameio import RawVideoSink
+            sink = RawVideoSink(outpath)
+        else:
+            sink = outpath
         num_frames = int((stoptime - starttime) * self.fps)
         tstart = int(starttime * self.fps)
         tend = tstart + num_frames
+        print("Starting to compute optimal Fov")
         fcorr, focalCenter = self._fov_terms(out_size, smoothingFocus, tstart, tend)
+        print("Done computing optimal Fov")
 
         mult, nblend = self.hyperlapse_multiplier, self.hyperlapse_num_blended_frames
-        if borderMode == cv.BORDER_TRANSPARENT or self.undistort.image_is_stretched():
+        if borderMode == cv.BORDER_TRANSPARENT:
             sequential = True
-        if world > 1 and borderMode == cv.BORDER_TRANSPARENT:
-            raise ValueError('bg_color="HISTORY" makes every frame depend on the previous output: it does not shard')
         lo, hi = frame_shard(max(num_frames - 1, 0), rank, world, mult)     # the loop runs i = 1 .. num_frames-1
+        stretched = self.undistort.image_is_stretched()
 
-        written = [0]
+        old_map_enable_setting = False
+        if viewer_thread is not None and display_preview:
+            old_map_enable_setting = getattr(viewer_thread, "map_function_enable", False)
+            viewer_thread.map_function_enable = False
+        if display_preview and viewer_thread is None:
+            print("Note: no preview window here (cv2.imshow); pass viewer_thread to receive preview frames")
+
+        state = dict(written=0, abort=False)
 
         def emit(frames):
             for f in frames:
-                sink.write(f)
-                written[0] += 1
+                if state["abort"]:
+                    return
+                try:
+                    sink.write(f)
+                except Exception as e:
+                    print("Failed to write frame. Aborting render")
+                    print(e)
+                    state["abort"] = True
+                    return
+                state["written"] += 1
+                if display_preview and viewer_thread is not None:
+                    try:
+                        fp = f
+                        if f.shape[1] > 1280:        # cv2.resize(..., INTER_NEAREST): source index = floor(dst * scale)
+                            ph = int(f.shape[0] * 1280 / f.shape[1])
+                            ys = np.minimum((np.arange(ph) * (f.shape[0] / ph)).astype(np.int64), f.shape[0] - 1)
+                            xs = np.minimum((np.arange(1280) * (f.shape[1] / 1280)).astype(np.int64), f.shape[1] - 1)
+                            fp = f[ys][:, xs]
+                        viewer_thread.frame = np.array(fp, copy=True)
+                        viewer_thread.update_once = True
+                    except Exception as e:
+                        print("Failed to display preview")
+                        print(e)
 
         dtype = None
         pipe = None
-        pend_frames, pend_xf = [], []          # frames of complete/incomplete groups waiting for a batch
-        seq = None                              # state of the sequential path
+        seq = None                              # state of the sequential path: frame_out, frame_temp (float64)
+
+        def seq_state():
+            nonlocal seq
+            if seq is None:
+                seq = dict(frame_out=None, frame_temp=torch.zeros((out_size[1], out_size[0], 3), dtype=torch.float64, device=self.device))
+            return seq
+
+        def seq_frame(frame, frame_num, phase, do_remap, do_emit):
+            """One iteration of the reference loop body (:1423-1468 and :1487) with its own kernels."""
+            st = seq_state()
+            reset = phase == 0 and nblend > 1          # frame_temp * 0.0 at the start of a hyperlapse group
+            if do_remap:
+                m1, m2 = self.undistort.get_maps(fov_scale * fcorr[frame_num], new_img_dim=self.orig_dimension, output_dim=out_size,
+                                                 update_new_K=False, quat=self.stab_transform[frame_num],
+                                                 focalCenter=focalCenter[frame_num], device=self.device)
+                src = frame.to(self.device) if isinstance(frame, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
+                st["frame_out"] = cv.remap(src, m1, m2, cv.INTER_LINEAR, dst=st["frame_out"], borderMode=borderMode,
+                                           borderValue=borderValue)
+                if nblend > 1:
+                    cv.blend_accumulate(st["frame_out"], st["frame_temp"], 1 / nblend, reset)
+            elif reset:
+                st["frame_temp"].mul_(0.0)
+            if do_emit and st["frame_out"] is not None:
+                if nblend > 1:
+                    st["frame_out"] = cv.blend_finalize(st["frame_temp"], dtype)
+                emit([st["frame_out"].cpu().numpy()])
+
+        # ---- batched path state
+        cur = dict(slot=None, n=0, fnums=[])    # the batch being staged
+        group = []                              # (frame, frame_num, phase, do_emit) of the hyperlapse group being collected
+        group_id = None
+        prev_clean = None                       # frames of the last group that went through the fused blend kernel
+        seq_valid = True                        # the sequential state reflects everything rendered so far
+
+        def xforms(fnums):
+            fn = np.asarray(fnums, np.int64)
+            return self.undistort.frame_xforms(fov_scale * fcorr[fn], self.stab_transform[fn], output_dim=out_size,
+                                               new_img_dim=self.orig_dimension, focalCenters=focalCenter[fn])
 
         def flush_batch():
-            nonlocal pend_frames, pend_xf
-            n_groups = len(pend_frames) // nblend
-            if n_groups == 0:
+            n = cur["n"]
+            if n == 0:
                 return
-            n = n_groups * nblend
-            frames, xf = pend_frames[:n], np.stack(pend_xf[:n])
-            pend_frames, pend_xf = pend_frames[n:], pend_xf[n:]
-            xf_dev = cv.xforms_to_device(xf, self.device)
+            slot, fnums = cur["slot"], cur["fnums"]
+            cur.update(slot=None, n=0, fnums=[])
+            n_groups = n // nblend
 
-            def launch(din, dout):
+            def launch(din, dout, dxf):
                 if nblend == 1:
-                    cv.undistort_rotate(din, self.undistort.D, xf_dev, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue)
+                    cv.undistort_rotate(din, self.undistort.D, dxf, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue)
                 else:
-                    cv.undistort_rotate_blend(din, self.undistort.D, xf_dev, out_size, nblend, nblend, dst=dout[:n_groups],
+                    cv.undistort_rotate_blend(din, self.undistort.D, dxf, out_size, nblend, nblend, dst=dout[:n_groups],
                                               borderMode=borderMode, borderValue=borderValue)
                 return n_groups
-            pipe.submit(frames, launch)
+            pipe.commit(slot, n, launch, xforms(fnums))
 
-        group_phases = []                       # phases seen in the current blend group (batched path)
-        for frame_num, frame, phase, do_remap, do_emit in self.schedule(tstart + lo, hi - lo, first_iter=lo):
-            if dtype is None:
-                dtype = torch.uint8 if frame.dtype == np.uint8 else torch.uint16
-            fov = fov_scale * fcorr[frame_num]
+        def stage(frame, frame_num):
+            nonlocal pipe
+            if pipe is None:
+                b = batch if batch else self.default_batch(frame.nbytes if hasattr(frame, "nbytes") else frame.numel() * frame.element_size())
+                out_batch = b if nblend == 1 else max(1, b // nblend)
+                pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (out_size[1], out_size[0]), dtype,
+                                     out_batch * nblend, emit, depth=pipeline_depth, out_batch=out_batch)
+            if cur["slot"] is None:
+                cur["slot"] = pipe.acquire()
+            pipe.stage(cur["slot"], cur["n"], frame)
+            cur["n"] += 1
+            cur["fnums"].append(frame_num)
+            if cur["n"] >= pipe.batch:
+                flush_batch()
 
-            if sequential:
-                if seq is None:
-                    seq = dict(frame_out=None, frame_temp=torch.zeros((out_size[1], out_size[0], 3), dtype=torch.float64, device=self.device))
-                reset = phase == 0 and nblend > 1          # frame_temp * 0.0 at the start of a hyperlapse group
+        def close_group():
+            """A finished hyperlapse group (nblend > 1): whole groups -- phases 0 .. nblend-1 all read -- go to the fused blend
+            kernel; a group with a failed read inside takes the reference's frame-by-frame sequence instead (there a
+            missing first frame also means a missing reset, so the accumulator of the previous group carries over)."""
+            nonlocal group, prev_clean, seq_valid
+            g, group = group, []
+            if not g:
+                return
+            if [e[2] for e in g] == list(range(nblend)):
+                for frame, frame_num, _, _ in g:
+                    stage(frame, frame_num)
+                prev_clean, seq_valid = [(e[0], e[1]) for e in g], False
+                return
+            flush_batch()
+            if pipe is not None:
+                pipe.flush()                    # keep the output order
+            if not seq_valid and prev_clean is not None and g[0][2] != 0:
+                for b, (frame, frame_num) in enumerate(prev_clean):      # rebuild frame_temp as the previous group left it
+                    seq_frame(frame, frame_num, b, True, False)
+            for frame, frame_num, phase, do_emit in g:
+                seq_frame(frame, frame_num, phase, True, do_emit)
+            prev_clean, seq_valid = None, True
+
+        try:
+            for frame_num, frame, phase, do_remap, do_emit, k in self.schedule(tstart + lo, hi - lo, first_iter=lo, with_iter=True):
+                if state["abort"]:
+                    break
+                if dtype is None:
+                    dtype = torch.uint8 if str(frame.dtype).endswith("uint8") else torch.uint16
+                if sequential or stretched:
+                    seq_frame(frame, frame_num, phase, do_remap, do_emit)
+                    continue
+                if nblend == 1:
+                    if do_remap:
+                        stage(frame, frame_num)
+                    continue
+                if group_id is not None and k // mult != group_id:
+                    close_group()
+                group_id = k // mult
                 if do_remap:
-                    m1, m2 = self.undistort.get_maps(fov, new_img_dim=self.orig_dimension, output_dim=out_size,
-                                                     update_new_K=False, quat=self.stab_transform[frame_num],
-                                                     focalCenter=focalCenter[frame_num], device=self.device)
-                    src = torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
-                    seq["frame_out"] = cv.remap(src, m1, m2, cv.INTER_LINEAR, dst=seq["frame_out"], borderMode=borderMode,
-                                                borderValue=borderValue)
-                    if nblend > 1:
-                        cv.blend_accumulate(seq["frame_out"], seq["frame_temp"], 1 / nblend, reset)
-                if do_emit and seq["frame_out"] is not None:
-                    if nblend > 1:
-                        seq["frame_out"] = cv.blend_finalize(seq["frame_temp"], dtype)
-                    emit([seq["frame_out"].cpu().numpy()])
-                continue
-
-            if do_remap:
-                if nblend > 1:
-                    # the fused blend kernel needs whole groups: phases 0..nblend-1 in order, no failed read between
-                    if phase == 0:
-                        group_phases = []
-                    group_phases.append(phase)
-                    if group_phases != list(range(len(group_phases))):
-                        raise NotImplementedError("failed read inside a hyperlapse blend group: render with sequential=True")
-                if pipe is None:
-                    out_batch = batch if nblend == 1 else max(1, batch // nblend)
-                    in_batch = out_batch * nblend
-                    pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (out_size[1], out_size[0]), dtype,
-                                         in_batch, emit, depth=pipeline_depth, out_batch=out_batch)
-                pend_frames.append(frame)
-                pend_xf.append(self._xform(fov, frame_num, out_size, focalCenter[frame_num]))
-                if len(pend_frames) >= pipe.batch:
-                    flush_batch()
-
-        if pipe is not None:
-            flush_batch()          # complete groups only; an unfinished trailing group emits nothing (as in the reference)
-            pipe.flush()
-        sink.close()
+                    group.append((frame, frame_num, phase, do_emit))
+            if not state["abort"]:
+                if nblend > 1 and not (sequential or stretched):
+                    # an unfinished trailing group emits nothing (as in the reference): only a group whose last blended frame
+                    # was read is closed
+                    if group and group[-1][3]:
+                        close_group()
+                flush_batch()
+                if pipe is not None:
+                    pipe.flush()
+        except KeyboardInterrupt:
+            print("terminating render")
         print("Render finished")
-        return written[0]
+        sink.close()
+        if viewer_thread is not None:
+            viewer_thread.map_function_enable = old_map_enable_setting
+        return state["written"]
 
 
 class OnlyUndistort:
@@ -441,9 +568,9 @@ class OnlyUndistort:
             if not pend:
                 return
             n = len(pend)
-            xf_dev = cv.xforms_to_device(np.tile(xf1, (n, 1)), self.device)
-            pipe.submit(pend, lambda din, dout: (cv.undistort_rotate(din, self.undistort.D, xf_dev, (map_w, map_h), dst=dout[:n],
-                                                                     borderMode=cv.BORDER_CONSTANT), n)[1])
+            pipe.submit(pend, lambda din, dout, dxf: (cv.undistort_rotate(din, self.undistort.D, dxf, (map_w, map_h), dst=dout[:n],
+                                                                          borderMode=cv.BORDER_CONSTANT), n)[1],
+                        xf=np.tile(xf1, (n, 1)))
             pend = []
 
         while True:

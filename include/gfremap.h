@@ -90,6 +90,12 @@ typedef struct gf_frame_xform {
 GF_API int gf_make_frame_xform(const double K_host[9], const double R_host[9], const double P_host[9],
                         gf_frame_xform* out_host);
 
+/* HOST helper: gf_make_frame_xform for the n frames of a batch in one call -- the lens matrix K (scaled_K) is the same for
+ * every frame, R_host and P_host hold n row-major 3x3 matrices each (per-frame rotation and new_K,
+ * calibrate_video.py:351-370).  Element i is bit-identical to gf_make_frame_xform(K, R[i], P[i]). */
+GF_API int gf_make_frame_xforms(const double K_host[9], const double* R_host, const double* P_host, size_t n,
+                         gf_frame_xform* out_host);
+
 /* cv2.fisheye.initUndistortRectifyMap(K, D, R, P, (out_w,out_h), cv2.CV_16SC2)
  *   replaces calibrate_video.py:383 (and :322 with R = I).  map1: int16 [out_h][out_w][2],
  *   map2: uint16 [out_h][out_w] = (fy<<5)|fx, INTER_BITS = 5.  xf is a HOST pointer. */

@@ -73,6 +73,13 @@ def _quats(n, seed=0):
     dict(bg="#000000", mult=1, nblend=1, fail_at=(4, 9, 10)),
     dict(bg="#000000", mult=2, nblend=2, sequential=True, fail_at=(5,)),
     dict(bg="#000000", mult=1, nblend=1, short_stab=True),
+    # failed reads inside hyperlapse blend groups on the batched path: the group falls back to the reference's sequence
+    # (first frame of a group missing -> no reset, the previous group's accumulator carries over; middle / last frame missing)
+    dict(bg="#000000", mult=2, nblend=2, fail_at=(5,), batch=4),
+    dict(bg="#203040", mult=4, nblend=3, fail_at=(6, 11, 16, 17), batch=6),
+    dict(bg="REPLICATE", mult=3, nblend=3, fail_at=(2, 3, 4, 13), batch=9),
+    dict(bg="#000000", mult=3, nblend=2, fail_at=(8, 9, 10, 11, 12), pinned=True),
+    dict(bg="#000000", mult=1, nblend=1, pinned=True, batch=7),
 ])
 def test_renderfile_matches_reference_loop(gpu, orc, mode):
     from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, synthetic_frames
@@ -86,11 +93,21 @@ def test_renderfile_matches_reference_loop(gpu, orc, mode):
     fail_at = mode.get("fail_at", ())
     fps, start, stop = 10.0, 0.2, 2.9
     out_size = (240, 136)
-    st = Stabilizer(ArraySource(frames, fail_at=fail_at), cal, stab, fps, w, h, device=gpu)
+    source = ArraySource(frames, fail_at=fail_at)
+    if mode.get("pinned"):                  # frames arrive as pinned tensors (a decoder's own pinned ring): no staging copy
+        from gyroflow_amd import PinnedRingSource
+
+        class FailingPinned(PinnedRingSource):
+            def read(self):
+                p = self.pos
+                ok, f = super().read()
+                return (False, None) if p in fail_at else (ok, f)
+        source = FailingPinned(frames, len(frames))
+    st = Stabilizer(source, cal, stab, fps, w, h, device=gpu)
     st.set_hyperlapse(mode["mult"], mode["nblend"])
     sink = ListSink()
     nw = st.renderfile(start, stop, sink, out_size=out_size, fov_scale=1.3, smoothingFocus=-2, bg_color=mode["bg"],
-                       batch=mode.get("batch", 8), sequential=mode.get("sequential", False))
+                       batch=mode.get("batch", 8), sequential=mode.get("sequential", False), pipeline_depth=mode.get("depth", 2))
     want = reference_loop(orc, cal, frames, set(fail_at), stab, fps, start, stop, out_size, 1.3, mode["bg"], mode["mult"],
                           mode["nblend"], (w, h))
     assert nw == len(sink.frames) == len(want) and nw > 0
@@ -198,3 +215,97 @@ def test_gyroflow_data_file_roundtrip(gpu, tmp_path):
     with open(str(tmp_path / "bad.gyroflow"), "w") as f:
         json.dump({"title": "x"}, f)
     assert st2.import_gyroflow_file(str(tmp_path / "bad.gyroflow")) is False
+
+
+def test_renderfile_reference_call_surface(gpu, orc, tmp_path):
+    """The reference's own call (gyroflow.py:2769-2773 -> stabilizer.py:1220-1222): every keyword it passes is accepted; a path
+    receives the frames (raw video instead of the ffmpeg pipe); a bad extension, debug_text and a sharded HISTORY render print
+    and return like the reference's early exits; a sink whose write fails stops the render without raising."""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, RawVideoSource, synthetic_frames
+    w, h, n = 338, 254, 20
+    frames = synthetic_frames(w, h, n=n, seed=11)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    stab = _quats(n + 2, seed=5)
+    st = Stabilizer(ArraySource(frames), cal, stab, 10.0, w, h, device=gpu)
+    out_size = (240, 136)
+    path = str(tmp_path / "Stabilized.mp4")
+
+    class Viewer:
+        map_function_enable = True
+        frame = None
+        update_once = False
+    viewer = Viewer()
+    nw = st.renderfile(0.0, 1.6, path, out_size=out_size, split_screen=False, bitrate_mbits=25, display_preview=True, scale=1,
+                       vcodec="h264_vaapi", vprofile="high", pix_fmt="yuv420p", debug_text=False, custom_ffmpeg="", smoothingFocus=-2,
+                       fov_scale=1.2, bg_color="#102030", audio=False, viewer_thread=viewer)
+    sink = ListSink()
+    assert st.renderfile(0.0, 1.6, sink, out_size, smoothingFocus=-2, fov_scale=1.2, bg_color="#102030") == nw == 15
+    got = RawVideoSource(path, out_size[0], out_size[1])
+    assert got.count == nw
+    for f in sink.frames:
+        np.testing.assert_array_equal(got.read()[1], f)
+    assert viewer.update_once and np.array_equal(viewer.frame, sink.frames[-1]) and viewer.map_function_enable is True
+    want = reference_loop(orc, cal, frames, set(), stab, 10.0, 0.0, 1.6, out_size, 1.2, "#102030", 1, 1, (w, h))
+    for a, b in zip(sink.frames, want):
+        np.testing.assert_array_equal(a, b)
+    # early exits
+    assert st.renderfile(0.0, 1.6, str(tmp_path / "x.txt"), out_size) is None
+    assert st.renderfile(0.0, 1.6, ListSink(), out_size, debug_text=True) is None
+    assert st.renderfile(0.0, 1.6, ListSink(), out_size, bg_color="HISTORY", world=2) is None
+
+    class BadSink:
+        n = 0
+
+        def write(self, f):
+            self.n += 1
+            if self.n == 4:
+                raise IOError("disk full")
+
+        def close(self):
+            self.closed = True
+    bad = BadSink()
+    assert st.renderfile(0.0, 1.6, bad, out_size, smoothingFocus=-2, batch=3) == 3 and bad.closed
+
+
+def test_batched_render_4k_transforms_stay_with_their_batch(gpu):
+    """Three batches of 3840x2160 frames with a different rotation per frame through the pinned pipeline: every output frame
+    equals a single-frame call with its own transform.  (Each pipeline slot owns its batch's transforms; they used to live in
+    a temporary that the next batch could overwrite before the kernel had run.)"""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, synthetic_frames, cv
+    w, h, n = 3840, 2160, 13
+    ring = synthetic_frames(w, h, n=2, seed=3)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero7_4k_169"))
+    stab = _quats(n + 1, seed=9)
+    st = Stabilizer(ArraySource(ring, count=n, ring=True), cal, stab, 30.0, w, h, device=gpu)
+    sink = ListSink()
+    nw = st.renderfile(0.0, (n + 0.5) / 30.0, sink, out_size=(w, h), smoothingFocus=-2, batch=4, pipeline_depth=2)
+    assert nw == n - 1
+    for k in range(nw):
+        xf = cv.xforms_to_device(cal.frame_xforms(1.0, stab[k:k + 1], output_dim=(w, h), new_img_dim=(w, h)), gpu)
+        one = cv.undistort_rotate(torch.from_numpy(ring[k % 2]).to(gpu), cal.D, xf, (w, h)).reshape(h, w, 3).cpu().numpy()
+        assert np.array_equal(sink.frames[k], one), "frame %d was rendered with another frame's transform" % k
+
+
+@pytest.mark.parametrize("mult,nblend", [(1, 1), (4, 2)])
+def test_two_rank_render_equals_single_rank(gpu, mult, nblend):
+    """renderfile(rank=0, world=2) + renderfile(rank=1, world=2) write the single-rank frames (frames are independent; shards
+    are aligned to hyperlapse groups) -- both shards run on the one GPU of this box."""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, synthetic_frames
+    w, h, n = 338, 254, 40
+    frames = synthetic_frames(w, h, n=n, seed=2)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    stab = _quats(n, seed=6)
+    outs = []
+    for rank, world in ((0, 1), (0, 2), (1, 2)):
+        st = Stabilizer(ArraySource(frames), cal, stab, 10.0, w, h, device=gpu)
+        st.set_hyperlapse(mult, nblend)
+        sink = ListSink()
+        st.renderfile(0.1, 3.8, sink, out_size=(240, 136), smoothingFocus=-2, bg_color="REPLICATE", batch=8, rank=rank, world=world)
+        outs.append(sink.frames)
+    single, r0, r1 = outs
+    assert len(r0) > 0 and len(r1) > 0 and len(r0) + len(r1) == len(single)
+    for a, b in zip(r0 + r1, single):
+        np.testing.assert_array_equal(a, b)

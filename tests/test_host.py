@@ -372,3 +372,24 @@ def test_rp_table_and_interpolation_error():
         got = sum(C[:, k][:, None] * zz[None, :] ** k for k in range(8))
         want = G(zz[None, :], eta[:, None])
         assert np.abs(got / want - 1).max() < tol, (dist, np.abs(got / want - 1).max())
+
+
+def test_renderfile_early_exits_need_no_gpu(capsys):
+    """The reference's renderfile prints and returns for a bad file extension (stabilizer.py:1230-1233); the mirror does the same
+    for that, for debug_text (cv2 drawing, not available) and for a sharded HISTORY render -- before any GPU work."""
+    import inspect
+    from gyroflow_amd import Stabilizer, ArraySource
+    frames = [np.zeros((4, 4, 3), np.uint8)] * 4
+    st = Stabilizer(ArraySource(frames), preset_path("hero8_27k_43"), np.tile([1.0, 0, 0, 0], (4, 1)), 10.0, 4, 4)
+    assert st.renderfile(0, 1, "movie.xyz") is None
+    assert "does not have a valid file extension" in capsys.readouterr().out
+    assert st.renderfile(0, 1, "/nonexistent_dir/movie.mp4", debug_text=True) is None
+    assert "debug_text" in capsys.readouterr().out
+    assert st.renderfile(0, 1, "/nonexistent_dir/movie.mp4", bg_color="HISTORY", world=2) is None
+    assert "does not shard" in capsys.readouterr().out
+    names = list(inspect.signature(Stabilizer.renderfile).parameters)
+    assert names[:19] == ["self", "starttime", "stoptime", "outpath", "out_size", "split_screen", "bitrate_mbits", "display_preview",
+                          "scale", "vcodec", "vprofile", "pix_fmt", "debug_text", "custom_ffmpeg", "smoothingFocus", "fov_scale",
+                          "bg_color", "audio", "viewer_thread"]
+    d = inspect.signature(Stabilizer.renderfile).parameters
+    assert d["outpath"].default == "Stabilized.mp4" and d["smoothingFocus"].default == 4.0 and d["split_screen"].default is False
