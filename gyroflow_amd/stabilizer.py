@@ -307,7 +307,7 @@ class Stabilizer:
     def renderfile(self, starttime, stoptime, outpath="Stabilized.mp4", out_size=(1920, 1080), split_screen=False,
                    bitrate_mbits=20, display_preview=False, scale=1, vcodec="libx264", vprofile="main", pix_fmt="",
                    debug_text=False, custom_ffmpeg="", smoothingFocus=4.0, fov_scale=1.0, bg_color="#000000", audio=True,
-                   viewer_thread=None, *, batch=None, pipeline_depth=2, sequential=False, rank=0, world=1):
+                   viewer_thread=None, *, batch=None, pipeline_depth=3, sequential=False, rank=0, world=1):
         """Render [starttime, stoptime) through the fused undistort+rotate kernel (reference: stabilizer.py:1220-1531, same
         positional and keyword arguments).  Returns the number of frames written (the reference returns None).
 
@@ -453,8 +453,16 @@ class Stabilizer:
             if pipe is None:
                 b = batch if batch else self.default_batch(frame.nbytes if hasattr(frame, "nbytes") else frame.numel() * frame.element_size())
                 out_batch = b if nblend == 1 else max(1, b // nblend)
-                pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (out_size[1], out_size[0]), dtype,
-                                     out_batch * nblend, emit, depth=pipeline_depth, out_batch=out_batch)
+                # the pinned ring is expensive to allocate (page-locking gigabytes): keep it between renders of the same shape
+                key = (frame.shape[0], frame.shape[1], out_size[1], out_size[0], dtype, out_batch * nblend, pipeline_depth, out_batch)
+                if getattr(self, "_pipe_key", None) == key:
+                    pipe = self._pipe
+                    pipe.deliver = emit
+                else:
+                    self._pipe = self._pipe_key = None
+                    pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (out_size[1], out_size[0]), dtype,
+                                         out_batch * nblend, emit, depth=pipeline_depth, out_batch=out_batch)
+                    self._pipe, self._pipe_key = pipe, key
             if cur["slot"] is None:
                 cur["slot"] = pipe.acquire()
             pipe.stage(cur["slot"], cur["n"], frame)

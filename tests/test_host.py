@@ -393,3 +393,24 @@ def test_renderfile_early_exits_need_no_gpu(capsys):
                           "bg_color", "audio", "viewer_thread"]
     d = inspect.signature(Stabilizer.renderfile).parameters
     assert d["outpath"].default == "Stabilized.mp4" and d["smoothingFocus"].default == 4.0 and d["split_screen"].default is False
+
+
+def test_numa_pinning_helpers(tmp_path):
+    """dist.pin_to_numa_node reads a node's cpulist from sysfs and intersects it with the current affinity mask; absent
+    files or an empty intersection change nothing."""
+    from gyroflow_amd import dist
+    assert dist._parse_cpulist("0-3,8,10-11\n") == {0, 1, 2, 3, 8, 10, 11}
+    before = os.sched_getaffinity(0)
+    assert dist.pin_to_numa_node(None) is None
+    assert dist.pin_to_numa_node(3, sysfs=str(tmp_path)) is None                 # no such node
+    nd = tmp_path / "devices" / "system" / "node" / "node0"
+    nd.mkdir(parents=True)
+    (nd / "cpulist").write_text("100000-100003\n")
+    assert dist.pin_to_numa_node(0, sysfs=str(tmp_path)) is None                 # empty intersection: unchanged
+    assert os.sched_getaffinity(0) == before
+    one = min(before)
+    (nd / "cpulist").write_text("%d\n" % one)
+    try:
+        assert dist.pin_to_numa_node(0, sysfs=str(tmp_path)) == {one} and os.sched_getaffinity(0) == {one}
+    finally:
+        os.sched_setaffinity(0, before)

@@ -26,12 +26,10 @@ hsrc = torch.from_numpy(np.stack(ring)).pin_memory()
 count = [0]
 def deliver(frames): count[0] += len(frames)
 pipe = BatchPipeline(dev, (h, w), (h, w), torch.uint8, B, deliver, depth=args.depth)
-xfs = [cv.xforms_to_device(cal.frame_xforms(1.0, z[(k * B + np.arange(B)) % len(z)], output_dim=(w, h), new_img_dim=(w, h)), dev)
-       for k in range(args.batches + 3)]
+xfs = [cal.frame_xforms(1.0, z[(k * B + np.arange(B)) % len(z)], output_dim=(w, h), new_img_dim=(w, h)) for k in range(args.batches + 3)]
 def run(nb, k0):
     for k in range(nb):
-        xf = xfs[k0 + k]
-        pipe.submit(hsrc, lambda din, dout, xf=xf: (cv.undistort_rotate(din, cal.D, xf, (w, h), dst=dout[:B]), B)[1])
+        pipe.submit(hsrc, lambda din, dout, dxf: (cv.undistort_rotate(din, cal.D, dxf, (w, h), dst=dout[:B]), B)[1], xf=xfs[k0 + k])
     pipe.flush()
 run(3, 0)
 torch.cuda.synchronize()
