@@ -10,12 +10,15 @@ sys.path.insert(0, ROOT)
 
 def test_algorithmic_bytes_match_survey():
     import bench
-    # C1 12.44 MB, C2 22.67 MB, C3 49.77 MB, C4 98.21 MB (two-pass), C5 input + output of one u16 frame
-    assert bench.algorithmic_bytes_per_frame("c1") == 6220800 + 6220800
-    assert bench.algorithmic_bytes_per_frame("c2") == 16451136 + 6220800
-    assert bench.algorithmic_bytes_per_frame("c3") == 24883200 * 2
-    assert bench.algorithmic_bytes_per_frame("c4") == 36000000 + 2 * 18662400 + 24883200
-    assert bench.algorithmic_bytes_per_frame("c5") == 2 * 95233536
+    # SURVEY.md 8(d), per OUTPUT frame: C1 12.44 MB, C2 22.67 MB, C3 49.77 MB, C4 98.21 MB two-pass / 60.88 MB fused,
+    # C5 476.17 MB (four u16 inputs blended in registers + one output)
+    assert bench.algorithmic_bytes_per_unit("c1") == 6220800 + 6220800
+    assert bench.algorithmic_bytes_per_unit("c2") == 16451136 + 6220800
+    assert bench.algorithmic_bytes_per_unit("c3") == 24883200 * 2
+    assert bench.algorithmic_bytes_per_unit("c4_twopass") == 36000000 + 2 * 18662400 + 24883200
+    assert bench.algorithmic_bytes_per_unit("c4") == 36000000 + 24883200
+    assert bench.algorithmic_bytes_per_unit("c5") == 4 * 95233536 + 95233536
+    assert bench.algorithmic_bytes_per_unit("c5_noblend") == 2 * 95233536
 
 
 def test_touched_footprint_is_bounded_and_sensible(orc):
