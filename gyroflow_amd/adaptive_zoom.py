@@ -7,8 +7,8 @@ Same class, method names, arguments and return values.  What differs is the exec
   * findFcorr / findFov are evaluated for all frames at once with numpy array arithmetic (same formulas, same
     order of operations per element); the 3-point 'quadratic' interp1d of adaptive_zoom.py:75 is the unique
     parabola through the three points, evaluated in Lagrange form.
-The per-frame methods (findFcorr, findFov, boundingPolygon, findFocalCenter, min_rolling) are kept with the
-reference's signatures."""
+The per-frame methods (findFcorr, findFov, boundingPolygon, min_rolling) are kept with the reference's signatures;
+findFocalCenter (adaptive_zoom.py:158-190) is dead code in the reference -- nothing calls it -- and has no mirror."""
 import numpy as np
 from scipy.spatial.transform import Rotation
 
@@ -29,12 +29,9 @@ class AdaptiveZoom:
         self.D = np.copy(fisheyeCalibrator.D)
         self.device = device
 
-    # ---- adaptive_zoom.py:27-31
+    # ---- adaptive_zoom.py:27-31: minimum over every window of `window` consecutive samples (last axis)
     def min_rolling(self, a, window, axis=1):
-        shape = a.shape[:-1] + (a.shape[-1] - window + 1, window)
-        strides = a.strides + (a.strides[-1],)
-        rolling = np.lib.stride_tricks.as_strided(a, shape=shape, strides=strides)
-        return np.min(rolling, axis=axis)
+        return np.lib.stride_tricks.sliding_window_view(np.asarray(a), int(window), axis=-1).min(axis=axis)
 
     # ---- adaptive_zoom.py:33-62, for [..., N, 2] polygons and [..., 2] centres at once
     @staticmethod
@@ -115,49 +112,14 @@ class AdaptiveZoom:
 
         return fovValues, cropCenterPositions
 
-    # ---- adaptive_zoom.py:158-190
-    def findFocalCenter(self, box, output_dim):
-        (mleft, mright, mtop, mbottom) = box
-        (output_width, output_height) = output_dim
-        (calib_width, calib_height) = self.calib_dimension
-        maxX = mright - mleft
-        maxY = mbottom - mtop
-        output_ratio = float(output_width) / float(output_height)
-        if maxX / output_ratio < maxY:
-            window_width = maxX
-            window_height = maxX / output_ratio
-            fX = mleft + window_width / 2
-            fY = calib_height / 2
-            if fY + window_height / 2 > mbottom:
-                fY = mbottom - window_height / 2
-            elif fY - window_height / 2 < mtop:
-                fY = mtop + window_height / 2
-        else:
-            window_height = maxY
-            window_width = maxY * output_ratio
-            fY = mtop + window_height / 2
-            fX = calib_width / 2
-            if fX + window_width / 2 > mright:
-                fX = mright - window_width / 2
-            elif fX - window_width / 2 < mleft:
-                fX = mleft + window_width / 2
-        return (fX, fY)
-
-    # ---- adaptive_zoom.py:193-228
+    # ---- adaptive_zoom.py:193-216: numPoints - 1 equally spaced points per image edge, clockwise from the top-left corner
     def _distorted_points(self, numPoints=9):
-        (original_width, original_height) = self.calib_dimension
-        pts = []
-        for i in range(numPoints - 1):
-            pts.append((i * (original_width / (numPoints - 1)), 0))
-        for i in range(numPoints - 1):
-            pts.append((original_width, i * (original_height / (numPoints - 1))))
-        for i in range(numPoints - 1):
-            p = numPoints - 1 - i
-            pts.append((p * (original_width / (numPoints - 1)), original_height))
-        for i in range(numPoints - 1):
-            p = numPoints - 1 - i
-            pts.append((0, p * (original_height / (numPoints - 1))))
-        return np.array(pts, np.float64)
+        (w, h) = self.calib_dimension
+        n = numPoints - 1
+        fwd, back = np.arange(n, dtype=np.float64), np.arange(n, 0, -1, dtype=np.float64)
+        xs = np.concatenate([fwd * (w / n), np.full(n, float(w)), back * (w / n), np.zeros(n)])
+        ys = np.concatenate([np.zeros(n), fwd * (h / n), np.full(n, float(h)), back * (h / n)])
+        return np.stack([xs, ys], axis=1)
 
     @staticmethod
     def _rotations(quats):

@@ -1,6 +1,14 @@
-"""Test-side restatement of the reference's AdaptiveZoom (/root/reference/adaptive_zoom.py:33-155,193-228), frame by
-frame as the reference runs it: scipy's interp1d for the 3-point quadratic, cv2.fisheye.undistortPoints replaced by the
-CPU oracle.  TEST INFRASTRUCTURE: the product (gyroflow_amd/adaptive_zoom.py) never imports this."""
+"""CPU oracle for the AdaptiveZoom row -- TEST INFRASTRUCTURE.  Only tests/ may import this; the product
+(gyroflow_amd/adaptive_zoom.py) never does.
+
+A frame-by-frame restatement of the reference's AdaptiveZoom, in the order the reference runs it:
+    bounding_polygon   /root/reference/adaptive_zoom.py:193-228 (32 boundary points -> cv2.fisheye.undistortPoints :220,
+                       here oracle/cv_oracle.c's undistort_points)
+    find_fcorr         adaptive_zoom.py:33-62
+    find_fov           adaptive_zoom.py:64-86 (scipy interp1d 'quadratic' through three points, as the reference)
+    compute            adaptive_zoom.py:88-155 (rolling minimum + Gaussian smoothing of the per-frame FOV)
+Pinned by the reference's own data: the fcorr column / min_fcorr of plugins/blender/GX016015.MP4.gyroflow
+(tests/test_oracle.py::test_undistort_points_pinned_by_gyroflow_sample)."""
 import numpy as np
 from scipy.interpolate import interp1d
 from scipy.spatial.transform import Rotation

@@ -1,12 +1,12 @@
 """AdaptiveZoom (adaptive_zoom.py:88-228) and cv2.fisheye.undistortPoints on the GPU against the per-frame restatement in
-tests/ref_adaptive_zoom.py (oracle undistortPoints + scipy interp1d).  float64 throughout; the only non-bit-exact
+oracle/ref_adaptive_zoom.py (oracle undistortPoints + scipy interp1d).  float64 throughout; the only non-bit-exact
 operation is tan() (device libm vs glibc), so the tolerance is 1e-9 px on points and 1e-10 relative on fov values."""
 import os
 
 import numpy as np
 import pytest
 
-import ref_adaptive_zoom as raz
+from oracle import ref_adaptive_zoom as raz
 from conftest import GOLDEN, preset_path
 
 pytestmark = pytest.mark.gpu

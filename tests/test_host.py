@@ -224,7 +224,7 @@ def test_lens_table_accuracy():
 def test_adaptive_zoom_host_math_matches_per_frame_restatement(orc):
     """The batched findFcorr/findFov arithmetic (numpy, no GPU) against the per-frame restatement with scipy's interp1d,
     on polygons produced by the oracle's undistortPoints."""
-    import ref_adaptive_zoom as raz
+    from oracle import ref_adaptive_zoom as raz
     from gyroflow_amd import FisheyeCalibrator
     from gyroflow_amd.adaptive_zoom import AdaptiveZoom
     z = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
@@ -242,9 +242,13 @@ def test_adaptive_zoom_host_math_matches_per_frame_restatement(orc):
         f1, i1 = raz.find_fcorr(centers[3], polys[3], od)
         assert f0 == f1 and i0 == i1
         assert az.findFov(centers[3], polys[3], od) == pytest.approx(want[3], rel=1e-12)
-    assert az.findFocalCenter((100, 3900, 50, 2950), (1920, 1080)) == (2000.0, 1500.0)
     a = np.arange(10.0)[::-1].copy()
     np.testing.assert_array_equal(az.min_rolling(a, 3), a[2:])
+    np.testing.assert_array_equal(az.min_rolling(np.array([3.0, 1.0, 4.0, 1.0, 5.0, 9.0, 2.0, 6.0]), 3), [1, 1, 1, 1, 2, 2])
+    # the boundary point list: 8 points per edge, clockwise from the top-left corner (adaptive_zoom.py:199-216)
+    p = az._distorted_points(9)
+    assert p.shape == (32, 2) and tuple(p[0]) == (0.0, 0.0) and tuple(p[8]) == (4000.0, 0.0) and tuple(p[16]) == (4000.0, 3000.0)
+    assert tuple(p[24]) == (0.0, 3000.0) and tuple(p[31]) == (0.0, 375.0) and tuple(p[1]) == (500.0, 0.0)
 
 
 def test_raw_video_adapters_roundtrip(tmp_path):

@@ -318,7 +318,7 @@ def test_undistort_points_pinned_by_gyroflow_sample(orc):
     plugins/blender/GX016015.MP4.gyroflow were produced by AdaptiveZoom.compute (smoothingFocus=2.0, out_size=(1920,1080):
     stabilizer.py:1574,1637-1640), i.e. by cv2.fisheye.undistortPoints on 32 boundary points per frame.  The file stores
     quaternions and fcorr rounded to 5 decimals, so the reproduction can only agree to ~1e-4."""
-    import ref_adaptive_zoom as raz
+    from oracle import ref_adaptive_zoom as raz
     z = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))
     st = z["stab_transform"]
     fov, centers, _ = raz.compute(orc, z["K"], z["D"], tuple(int(v) for v in z["calib_dimension"]), st[:, 3:7], (1920, 1080),
