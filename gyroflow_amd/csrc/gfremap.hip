@@ -17,10 +17,12 @@
 //    writes two 384-B row segments = whole 128-B lines); a 256-thread workgroup covers a 128x32 output tile in four
 //    passes of 8 rows; workgroups are persistent and walk (frame, tile) work items.  The fixed-point map (INTER_BITS=5)
 //    lives in registers only.
-//  * Source taps are gathered through L1/L2 with unaligned 8-byte loads; workgroups are dealt to XCDs in contiguous
-//    bands of tile rows so that each XCD's L2 sees one horizontal band of the source frame.
-//  * Two alternative variants of the fused kernel (gf_ctx_set_kernel_mode) trade that design's costs differently: RP takes
-//    the coordinates from per-row polynomials, RL additionally stages the source box of a tile in LDS by LDS-DMA.
+//  * Source taps are gathered through L1/L2 with dword-aligned 12-byte loads (16 bytes for u16) that v_alignbyte_b32 shifts into
+//    place; workgroups are dealt to XCDs in contiguous bands of tile rows so that each XCD's L2 sees one horizontal band of
+//    the source frame.
+//  * Three variants of the fused kernel (gf_ctx_set_kernel_mode): RP -- the default -- takes the coordinates from per-tile
+//    polynomials (64 x 64 tiles) instead of the per-pixel table lookup described above (DIRECT); RL additionally stages the
+//    source box of a tile in LDS by LDS-DMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -89,10 +91,10 @@ static_assert(RL_ROWS % 4 == 0, "four rows per LDS-DMA instruction");
 
 thread_local char g_err[512] = "";
 // Kernel variants of the fused kernel and the CV_16SC2 map kernel (gf_ctx_set_kernel_mode; the environment variable GF_K1
-// = direct | rp | rl sets the default of new contexts): direct = per-pixel lens-table coordinates (kernel v4, the fastest
-// as measured on MI355X and the default), rp = RP coordinates (per-row polynomials) with taps gathered from the frame,
-// rl = RP coordinates and, for u8 frames, source taps staged through LDS by LDS-DMA.  The kernels of a mode use the same
-// coordinate arithmetic, so fused output == maps + remap bit for bit in every mode.
+// = direct | rp | rl, read once when the library is loaded, sets the default of new contexts): rp = RP coordinates (per-tile
+// polynomials) with taps gathered from the frame -- the default and the fastest as measured on MI355X; direct = per-pixel
+// lens-table coordinates; rl = RP coordinates and, for u8 frames, source taps staged through LDS by LDS-DMA.  The kernels of a
+// mode use the same coordinate arithmetic, so fused output == maps + remap bit for bit in every mode.
 const int g_k1_mode = !getenv("GF_K1") ? GF_KERNEL_RP : !strcmp(getenv("GF_K1"), "direct") ? GF_KERNEL_DIRECT : !strcmp(getenv("GF_K1"), "rl") ? GF_KERNEL_RL : GF_KERNEL_RP;
 // Persistent grid of the RP kernel, workgroups per CU (4 are resident).  0 = by launch size: 16, or 32 once that still leaves
 // every workgroup 24 or more work items -- a finer split shortens the tail of partly idle CUs at the end of a launch (measured on
@@ -112,12 +114,18 @@ int fail(int code, const char* fmt, const char* a = "", long long b = 0)
         if (e_ != hipSuccess) return fail(GF_ERR_HIP, "%s failed: HIP error %lld", #expr, (long long)e_); \
     } while (0)
 
+constexpr int LENS_EVENTS = 4;
 struct LensSlot {
     double D[4];
     bool valid;
     double* dev;          // LENS_DOUBLES doubles
     double* host;         // pinned staging
     unsigned long long last_use;
+    // the last launch that read this table on each of up to LENS_EVENTS streams: what an eviction has to wait for
+    hipEvent_t ev[LENS_EVENTS];
+    hipStream_t ev_stream[LENS_EVENTS];
+    bool ev_used[LENS_EVENTS];
+    bool ev_overflow;     // more streams than events have used the slot: an eviction falls back to a device synchronise
 };
 
 struct Ctx {
@@ -2102,9 +2110,33 @@ Xf to_xf(const gf_frame_xform* x)
     return r;
 }
 
-// Device lens table for distortion coefficients D: a hit in the context's 4-slot cache costs nothing; a miss builds
-// the table on the host (~1 ms), uploads it on `stream` and waits for the upload (once per lens).
-int get_lens(Ctx* c, const double* D, hipStream_t stream, const double** dev, LensK* lk)
+// Device lens table for distortion coefficients D: a hit in the context's 4-slot cache costs nothing; a miss builds the
+// table on the host (~1 ms), uploads it on `stream` and waits for the upload (once per lens).
+// LensLease holds the context's mutex from the lookup until the launch that uses the table has been queued and then records
+// an event behind that launch, so that a later eviction of the slot (a fifth distinct D) waits for exactly the launches
+// that may still read it -- not for the whole device, and never for a launch that has not been queued yet.
+struct LensLease {
+    Ctx* c;
+    hipStream_t stream;
+    int slot;
+    std::unique_lock<std::mutex> lock;
+    LensLease(Ctx* ctx, hipStream_t st) : c(ctx), stream(st), slot(-1), lock(ctx->mu) {}
+    int mode() const { return c->k1_mode; }
+    int acquire(const double* D, const double** dev, LensK* lk);
+    ~LensLease()
+    {
+        if (slot < 0) return;
+        LensSlot& s = c->lens[slot];
+        int e = -1;
+        for (int i = 0; i < LENS_EVENTS; i++) if (s.ev_used[i] && s.ev_stream[i] == stream) { e = i; break; }
+        if (e < 0) for (int i = 0; i < LENS_EVENTS; i++) if (!s.ev_used[i]) { e = i; break; }
+        if (e < 0) { s.ev_overflow = true; return; }
+        if (hipEventRecord(s.ev[e], stream) == hipSuccess) { s.ev_used[e] = true; s.ev_stream[e] = stream; }
+        else s.ev_overflow = true;
+    }
+};
+
+int LensLease::acquire(const double* D, const double** dev, LensK* lk)
 {
     if (!D) return fail(GF_ERR_INVALID_ARG, "%s: null distortion coefficients", "lens");
     for (int i = 0; i < 4; i++) {
@@ -2115,26 +2147,31 @@ int get_lens(Ctx* c, const double* D, hipStream_t stream, const double** dev, Le
         const double tm = atan(sqrt((double)((1 << LENS_OCT) - 1))), t2 = tm*tm;
         lk->bound = tm*(1 + t2*(fabs(D[0]) + t2*(fabs(D[1]) + t2*(fabs(D[2]) + t2*fabs(D[3])))));
     }
-    std::lock_guard<std::mutex> g(c->mu);
     c->tick++;
-    int lru = 0;
-    for (int i = 0; i < LENS_SLOTS; i++) {
+    int victim = -1;
+    for (int i = 0; i < LENS_SLOTS; i++) {               // every slot is looked at: a hit may sit behind an empty slot
         LensSlot& s = c->lens[i];
-        if (s.valid && memcmp(s.D, D, sizeof s.D) == 0) { s.last_use = c->tick; *dev = s.dev; return GF_OK; }
-        if (!s.valid) { lru = i; break; }
-        if (s.last_use < c->lens[lru].last_use) lru = i;
+        if (s.valid && memcmp(s.D, D, sizeof s.D) == 0) { s.last_use = c->tick; *dev = s.dev; slot = i; return GF_OK; }
     }
-    LensSlot& s = c->lens[lru];
-    if (s.valid) {                       // evicting a table that launches on other streams may still be reading
-        HIP_TRY(hipDeviceSynchronize());
+    for (int i = 0; i < LENS_SLOTS; i++) if (!c->lens[i].valid) { victim = i; break; }
+    if (victim < 0) {
+        victim = 0;
+        for (int i = 1; i < LENS_SLOTS; i++) if (c->lens[i].last_use < c->lens[victim].last_use) victim = i;
+    }
+    LensSlot& s = c->lens[victim];
+    if (s.valid) {                       // launches queued earlier (the mutex is ours: none is in the making) may still read the table
         s.valid = false;
+        if (s.ev_overflow) HIP_TRY(hipDeviceSynchronize());
+        for (int i = 0; i < LENS_EVENTS; i++) if (s.ev_used[i]) HIP_TRY(hipEventSynchronize(s.ev[i]));
     }
+    for (int i = 0; i < LENS_EVENTS; i++) s.ev_used[i] = false;
+    s.ev_overflow = false;
     build_lens_table(D, s.host);
     HIP_TRY(hipMemcpyAsync(s.dev, s.host, LENS_DOUBLES*sizeof(double), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     memcpy(s.D, D, sizeof s.D);
     s.valid = true; s.last_use = c->tick;
-    *dev = s.dev;
+    *dev = s.dev; slot = victim;
     return GF_OK;
 }
 
@@ -2194,7 +2231,11 @@ GF_API int gf_ctx_create(int device, void** ctx)
     if (!c) return fail(GF_ERR_HIP, "%s: out of host memory", "gf_ctx_create");
     c->device = device; c->cubic_tab = nullptr; c->rp_tab = nullptr; c->tick = 0; c->n_cu = 0; c->k1_mode = g_k1_mode;
     if (hipDeviceGetAttribute(&c->n_cu, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || c->n_cu <= 0) c->n_cu = 256;
-    for (int i = 0; i < LENS_SLOTS; i++) { c->lens[i].valid = false; c->lens[i].dev = nullptr; c->lens[i].host = nullptr; c->lens[i].last_use = 0; }
+    for (int i = 0; i < LENS_SLOTS; i++) {
+        LensSlot& s = c->lens[i];
+        s.valid = false; s.dev = nullptr; s.host = nullptr; s.last_use = 0; s.ev_overflow = false;
+        for (int k = 0; k < LENS_EVENTS; k++) { s.ev[k] = nullptr; s.ev_used[k] = false; s.ev_stream[k] = nullptr; }
+    }
     hipError_t e = hipMalloc((void**)&c->cubic_tab, sizeof g_cubic_host);
     if (e == hipSuccess) e = hipMemcpy(c->cubic_tab, g_cubic_host, sizeof g_cubic_host, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void**)&c->rp_tab, RP_TAB_DOUBLES*sizeof(double));
@@ -2206,6 +2247,7 @@ GF_API int gf_ctx_create(int device, void** ctx)
     for (int i = 0; i < LENS_SLOTS && e == hipSuccess; i++) {
         e = hipMalloc((void**)&c->lens[i].dev, LENS_DOUBLES*sizeof(double));
         if (e == hipSuccess) e = hipHostMalloc((void**)&c->lens[i].host, LENS_DOUBLES*sizeof(double), hipHostMallocDefault);
+        for (int k = 0; k < LENS_EVENTS && e == hipSuccess; k++) e = hipEventCreateWithFlags(&c->lens[i].ev[k], hipEventDisableTiming);
     }
     if (e != hipSuccess) {
         gf_ctx_destroy(c);
@@ -2219,6 +2261,7 @@ GF_API int gf_ctx_set_kernel_mode(void* ctx, int mode)
 {
     if (!ctx) return fail(GF_ERR_INVALID_ARG, "%s: null ctx", "gf_ctx_set_kernel_mode");
     if (mode != GF_KERNEL_DIRECT && mode != GF_KERNEL_RP && mode != GF_KERNEL_RL) return fail(GF_ERR_INVALID_ARG, "gf_ctx_set_kernel_mode: unknown mode %s%lld", "", mode);
+    std::lock_guard<std::mutex> g(((Ctx*)ctx)->mu);
     ((Ctx*)ctx)->k1_mode = mode;
     return GF_OK;
 }
@@ -2227,11 +2270,13 @@ GF_API int gf_ctx_destroy(void* ctx)
 {
     if (!ctx) return GF_OK;
     Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
     if (c->cubic_tab) (void)hipFree(c->cubic_tab);
     if (c->rp_tab) (void)hipFree(c->rp_tab);
     for (int i = 0; i < LENS_SLOTS; i++) {
         if (c->lens[i].dev) (void)hipFree(c->lens[i].dev);
         if (c->lens[i].host) (void)hipHostFree(c->lens[i].host);
+        for (int k = 0; k < LENS_EVENTS; k++) if (c->lens[i].ev[k]) (void)hipEventDestroy(c->lens[i].ev[k]);
     }
     delete c;
     return GF_OK;
@@ -2280,8 +2325,10 @@ static int maps_common(void* ctx, const double* D, const gf_frame_xform* xf, int
         return fail(GF_ERR_INVALID_ARG, "%s: map step/alignment invalid (step1=%lld)", "gf_fisheye_maps", (long long)s1);
     Ctx* c = (Ctx*)ctx;
     DeviceGuard dg(c->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "gf_fisheye_maps");
     const double* lens; LensK lk;
-    int rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
+    LensLease lease(c, (hipStream_t)stream);
+    int rc = lease.acquire(D, &lens, &lk); if (rc) return rc;
     dim3 grid((w + 63)/64, (h + 63)/64);
     if (fixed && c->k1_mode != GF_KERNEL_DIRECT) hipLaunchKernelGGL(k_fisheye_maps_rp, dim3((w + RT - 1)/RT, (h + RT - 1)/RT), dim3(BLOCK), 0, (hipStream_t)stream,
                                                     to_xf(xf), lk, lens, (const double*)c->rp_tab, w, h, (uint8_t*)m1, s1, (uint8_t*)m2, s2);
@@ -2314,6 +2361,7 @@ GF_API int gf_convert_maps_32f_16sc2(void* ctx, const float* mx, size_t mxs, con
     if (sxd == 0.f || syd == 0.f) return fail(GF_ERR_INVALID_ARG, "%s: zero scale denominator", "gf_convert_maps_32f_16sc2");
     const int scale_on = !(sxn == 1.f && sxd == 1.f && syn == 1.f && syd == 1.f);
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     dim3 grid((w + 63)/64, (h + 3)/4);
     hipLaunchKernelGGL(k_convert_maps, grid, dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)mx, mxs, (const uint8_t*)my, mys,
                        sxn, sxd, syn, syd, scale_on, w, h, (uint8_t*)map1, s1, (uint8_t*)map2, s2);
@@ -2335,6 +2383,7 @@ GF_API int gf_remap_linear_c3(void* ctx, int depth, const void* src, int sw, int
         return fail(GF_ERR_INVALID_ARG, "%s: map step/alignment invalid (step1=%lld)", "gf_remap_linear_c3", (long long)s1);
     if (ranges_overlap(src, sstep*sh, dst, dstep*dh)) return fail(GF_ERR_INVALID_ARG, "%s: src and dst overlap", "gf_remap_linear_c3");
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     RemapArgs A = make_args(depth, src, sw, sh, sstep, 0, dst, dw, dh, dstep, 0, bv);
     dim3 grid(A.tiles_x*A.tiles_y, 1);
     DISPATCH_DEPTH_BORDER(k_remap_linear, depth, border, grid, (hipStream_t)stream, A, (const uint8_t*)map1, s1, (const uint8_t*)map2, s2);
@@ -2360,6 +2409,7 @@ GF_API int gf_remap_cubic_u8c3_f32maps(void* ctx, const uint8_t* src, int sw, in
     if (ranges_overlap(src, sstep*sh, dst, dstep*dh)) return fail(GF_ERR_INVALID_ARG, "%s: src and dst overlap", "gf_remap_cubic_u8c3_f32maps");
     int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     dim3 grid((dw + 63)/64, (dh + 3)/4);
     hipLaunchKernelGGL(k_remap_cubic_u8c3, grid, dim3(BLOCK), 0, (hipStream_t)stream, src, sw, sh, sstep, dst, dw, dh, dstep,
                        (const uint8_t*)mx, mxs, (const uint8_t*)my, mys, ((Ctx*)ctx)->cubic_tab, border, cval[0], cval[1], cval[2]);
@@ -2377,6 +2427,7 @@ GF_API int gf_superview_cubic_u8c3(void* ctx, const uint8_t* src, int sw, int sh
     if (!mapy_col || ((uintptr_t)mapx_row & 3) || ((uintptr_t)mapy_col & 3)) return fail(GF_ERR_INVALID_ARG, "%s: null or misaligned map", "gf_superview_cubic_u8c3");
     int cval[3]; cval_from(bv, GF_DEPTH_U8, cval);
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     Ctx* c = (Ctx*)ctx;
     const unsigned strips_x = (unsigned)(dw + BLOCK - 1)/BLOCK, strips_y = (unsigned)(dh + SV_ROWS - 1)/SV_ROWS;
     const unsigned long long n_work = (unsigned long long)strips_x*strips_y*(unsigned)n_frames;
@@ -2418,8 +2469,8 @@ static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, i
 {
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
     if (c->k1_mode != GF_KERNEL_DIRECT) {
-        // RP coordinates on 64 x 64 tiles; u8 frames with 16-byte aligned base, row pitch and frame stride also stage their
-        // source taps through LDS (mode 2, the default)
+        // RP coordinates on 64 x 64 tiles (mode RP, the default); in mode RL u8 frames with 16-byte aligned base, row pitch and
+        // frame stride also stage their source taps through LDS
         A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
         const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
         const unsigned long long n_work = (unsigned long long)tiles_pad*(unsigned)n_frames;
@@ -2472,8 +2523,10 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     if (rc) return rc;
     Ctx* c = (Ctx*)ctx;
     DeviceGuard dg(c->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "gf_undistort_rotate_c3");
     const double* lens; LensK lk;
-    rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
+    LensLease lease(c, (hipStream_t)stream);
+    rc = lease.acquire(D, &lens, &lk); if (rc) return rc;
     const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
     return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
                         border, bv, (hipStream_t)stream);
@@ -2483,7 +2536,7 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
 // gf_undistort_rotate_c3_noalloc: gf_undistort_rotate_c3 for callers that cannot allocate (HIP graph capture, tight serving
 // loops, harnesses that forbid hipMalloc).  It needs no context: the device memory the fused kernel uses beyond its inputs and
 // outputs -- the lens table, the RP table and the per-frame transforms -- lives in `scratch`, a static device array that
-// every GPU the library runs on holds until the process ends.  The tables are built on the host exactly as get_lens() /
+// every GPU the library runs on holds until the process ends.  The tables are built on the host exactly as LensLease::acquire() /
 // gf_ctx_create() build them and reach the device as kernel arguments (k_scratch_put: 2 KB per launch), so the call makes
 // no hipMalloc / hipFree / hipMemcpy and queues nothing but kernels on the caller's stream.
 // `scratch` is a host-side stand-in in host code, not a device address: hipGetSymbolAddress gives the address, once per
@@ -2545,7 +2598,7 @@ GF_API int gf_undistort_rotate_c3_noalloc(int device, int depth, const void* src
         if (!(D[i] == D[i]) || fabs(D[i]) > 1e6) return fail(GF_ERR_INVALID_ARG, "lens: distortion coefficient %s%lld is not finite", "", i);
         lk.k[i] = D[i];
     }
-    {   // as get_lens()
+    {   // as LensLease::acquire()
         const double tm = atan(sqrt((double)((1 << LENS_OCT) - 1))), t2 = tm*tm;
         lk.bound = tm*(1 + t2*(fabs(D[0]) + t2*(fabs(D[1]) + t2*(fabs(D[2]) + t2*fabs(D[3])))));
     }
@@ -2587,8 +2640,10 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
     if (rc) return rc;
     Ctx* c = (Ctx*)ctx;
     DeviceGuard dg(c->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "gf_undistort_rotate_blend_c3");
     const double* lens; LensK lk;
-    rc = get_lens(c, D, (hipStream_t)stream, &lens, &lk); if (rc) return rc;
+    LensLease lease(c, (hipStream_t)stream);
+    rc = lease.acquire(D, &lens, &lk); if (rc) return rc;
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
     if (c->k1_mode != GF_KERNEL_DIRECT && n_blend <= RB_MAX) {      // RP coordinates, as the fused kernel of this mode
         A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
@@ -2620,6 +2675,7 @@ GF_API int gf_blend_accumulate(void* ctx, int depth, const void* frame, double* 
     if (!frame || !acc || n == 0) return fail(GF_ERR_INVALID_ARG, "%s: null pointer or n == 0", "gf_blend_accumulate");
     if (((uintptr_t)acc & 7) || (depth == GF_DEPTH_U16 && ((uintptr_t)frame & 1))) return fail(GF_ERR_INVALID_ARG, "%s: misaligned buffer", "gf_blend_accumulate");
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     const unsigned blocks = (unsigned)((n + BLOCK - 1)/BLOCK < 8192 ? (n + BLOCK - 1)/BLOCK : 8192);
     if (depth == GF_DEPTH_U8) hipLaunchKernelGGL(k_blend_acc<uint8_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)frame, acc, weight, reset, n);
     else                      hipLaunchKernelGGL(k_blend_acc<uint16_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, (const uint16_t*)frame, acc, weight, reset, n);
@@ -2634,6 +2690,7 @@ GF_API int gf_blend_finalize(void* ctx, int depth, const double* acc, void* out,
     if (!acc || !out || n == 0) return fail(GF_ERR_INVALID_ARG, "%s: null pointer or n == 0", "gf_blend_finalize");
     if (((uintptr_t)acc & 7) || (depth == GF_DEPTH_U16 && ((uintptr_t)out & 1))) return fail(GF_ERR_INVALID_ARG, "%s: misaligned buffer", "gf_blend_finalize");
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     const unsigned blocks = (unsigned)((n + BLOCK - 1)/BLOCK < 8192 ? (n + BLOCK - 1)/BLOCK : 8192);
     if (depth == GF_DEPTH_U8) hipLaunchKernelGGL(k_blend_fin<uint8_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, acc, (uint8_t*)out, n);
     else                      hipLaunchKernelGGL(k_blend_fin<uint16_t>, dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, acc, (uint16_t*)out, n);
@@ -2654,6 +2711,7 @@ GF_API int gf_fisheye_undistort_points(void* ctx, const double* pts, size_t n_pt
     for (int i = 0; i < 4; i++) P.k[i] = D_host[i];
     if (P.f[0] == 0 || P.f[1] == 0) return fail(GF_ERR_SINGULAR, "%s: zero focal length", "gf_fisheye_undistort_points");
     DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "libgfremap");
     const size_t total = n_pts*n_sets;
     const size_t blocks = (total + BLOCK - 1)/BLOCK;
     if (blocks > 0x7fffffffull) return fail(GF_ERR_UNSUPPORTED, "%s: too many points", "gf_fisheye_undistort_points");

@@ -61,12 +61,12 @@ GF_API const char* gf_last_error(void);
 GF_API int gf_ctx_create(int device, void** ctx);
 GF_API int gf_ctx_destroy(void* ctx);
 
-/* Kernel variant used by gf_undistort_rotate_c3 and gf_fisheye_maps_16sc2 of this context (no counterpart in the reference:
- * an A/B switch; results are the same to the tolerance documented in DESIGN.md, and fused == maps + remap bit for bit in
- * every mode).  DIRECT: per-pixel lens-table coordinates, taps gathered from the frame (default).  RP: coordinates from
- * per-row polynomials on 64 x 64 tiles.  RL: RP coordinates + source taps staged through LDS by LDS-DMA (u8 frames with
- * 16-byte aligned base / pitch / frame stride; other inputs run as RP).  Not thread-safe against concurrent launches on
- * the same context. */
+/* Kernel variant used by gf_undistort_rotate_c3, gf_undistort_rotate_blend_c3 and gf_fisheye_maps_16sc2 of this context (no
+ * counterpart in the reference: an A/B switch; results are the same to the tolerance documented in DESIGN.md, and fused ==
+ * maps + remap bit for bit in every mode).  RP (the default): coordinates from per-tile polynomials on 64 x 64 tiles, taps
+ * gathered from the frame with aligned 12-byte loads.  DIRECT: per-pixel lens-table coordinates, same taps.  RL: RP
+ * coordinates + source taps staged through LDS by LDS-DMA (u8 frames with 16-byte aligned base / pitch / frame stride; other
+ * inputs run as RP).  The switch takes the context's mutex; launches already queued keep the variant they were queued with. */
 #define GF_KERNEL_DIRECT 0
 #define GF_KERNEL_RP     1
 #define GF_KERNEL_RL     2
@@ -77,7 +77,8 @@ GF_API int gf_ctx_set_kernel_mode(void* ctx, int mode);
  * coefficients D = (k1..k4) belong to the lens, not the frame: the calls below take them as 4 HOST doubles and keep a
  * per-context table of the radial scale function theta_d(atan r)/r for each distinct D (up to 4 lenses cached; the
  * first call with a new D builds the 16 KB table on the host, uploads it on the call's stream and waits for that
- * upload -- every later call is asynchronous). */
+ * upload -- every later call is asynchronous; a fifth distinct D evicts the least recently used table after waiting, on
+ * per-slot events, for the launches that read it).  A context may be used from several threads and streams at once. */
 typedef struct gf_frame_xform {
     double iR[9];
     double f[2];

@@ -477,3 +477,28 @@ def test_degenerate_transforms_match_oracle(gpu, orc):
                 m1, m2 = orc.fisheye_init_undistort_rectify_map(Kk, D, np.eye(3), np.eye(3), (dw, dh), orc.CV_16SC2, iR=x[:9].reshape(3, 3))
             want = orc.remap_linear(src, m1, m2, dst=prev.copy(), borderMode=border, borderValue=(1, 2, 3))
             assert np.array_equal(got[k], want), "degenerate case %d, border %d" % (k, border)
+
+
+def test_lens_cache_eviction_keeps_results(gpu):
+    """Six lenses through a context that caches four: every miss evicts the least recently used table after waiting for the
+    launches that read it (per-slot events), and a lens that comes back gives the bytes it gave the first time."""
+    from gyroflow_amd import cv, _lib
+    rng = np.random.default_rng(5)
+    w, h = 640, 360
+    K = np.array([[300., 0, 320], [0, 300., 180], [0, 0, 1]])
+    xf = cv.xforms_to_device(_lib.xform_to_array(_lib.make_frame_xform(K, np.eye(3), K))[None], gpu)
+    src = torch.from_numpy(_rand_img(rng, h, w, np.uint8)).to(gpu)
+    lenses = [[0.01 * (i + 1), -0.002 * i, 0.001, 0.0005 * i] for i in range(6)]
+    s2 = torch.cuda.Stream(gpu)
+    first = []
+    for D in lenses:
+        first.append(cv.undistort_rotate(src, D, xf, (w, h)).clone())
+    assert not torch.equal(first[0], first[5])
+    for rep in range(3):
+        for i in (3, 0, 5, 1, 4, 2):
+            with torch.cuda.stream(s2 if (i + rep) % 2 else torch.cuda.current_stream(gpu)):
+                got = cv.undistort_rotate(src, lenses[i], xf, (w, h))
+                m1, m2 = cv.fisheye_initUndistortRectifyMap(K, lenses[i], np.eye(3), K, (w, h), cv.CV_16SC2, device=gpu)
+            torch.cuda.synchronize(gpu)
+            assert torch.equal(got, first[i]), (rep, i)
+            assert torch.equal(cv.remap(src, m1, m2, cv.INTER_LINEAR), first[i].reshape(h, w, 3))

@@ -418,3 +418,22 @@ def test_numa_pinning_helpers(tmp_path):
         assert dist.pin_to_numa_node(0, sysfs=str(tmp_path)) == {one} and os.sched_getaffinity(0) == {one}
     finally:
         os.sched_setaffinity(0, before)
+
+
+def test_library_has_no_forbidden_instruction():
+    """The build refuses device code that contains v_ashr_pk_u8_i32 (gyroflow_amd/csrc/Makefile); check the library that ships."""
+    import shutil
+    import subprocess
+    import tempfile
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    if not os.path.exists(objdump):
+        pytest.skip("llvm-objdump not installed")
+    from gyroflow_amd import _lib
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(_lib.LIB_PATH, os.path.join(d, "lib.so"))
+        subprocess.check_call([objdump, "--offloading", "lib.so"], cwd=d, stdout=subprocess.DEVNULL)
+        cos = [f for f in os.listdir(d) if "amdgcn" in f]
+        assert cos, "no gfx950 code object in the library"
+        dis = subprocess.check_output([objdump, "-d", os.path.join(d, cos[0])]).decode()
+    assert "v_dot4_u32_u8" in dis            # the disassembly is the device code of the fused kernel
+    assert "v_ashr_pk_u8_i32" not in dis
