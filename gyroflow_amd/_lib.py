@@ -11,6 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgfremap.so")
 
 GF_OK = 0
+GF_ERR_INVALID_ARG, GF_ERR_HIP, GF_ERR_UNSUPPORTED, GF_ERR_SINGULAR = -1, -2, -3, -4
 DEPTH_U8, DEPTH_U16 = 0, 2
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_TRANSPARENT = 0, 1, 5
 
@@ -48,6 +49,7 @@ SIGNATURES = {
     "gf_remap_cubic_u8c3_f32maps": [_vp, _vp, _i, _i, _sz, _vp, _i, _i, _sz, _vp, _sz, _vp, _sz, _i, _dp, _vp],
     "gf_superview_cubic_u8c3": [_vp, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _vp, _vp, _i, _i, _dp, _vp],
     "gf_undistort_rotate_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _dp, _vp],
+    "gf_undistort_rotate_superview_u8c3": [_vp, _vp, _i, _i, _sz, _sz, _i, _i, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _vp, _vp, _i, _dp, _vp],
     "gf_undistort_rotate_c3_noalloc": [_i, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _dp, _vp],
     "gf_undistort_rotate_blend_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _i, _i, _dp, _vp],
     "gf_blend_accumulate": [_vp, _i, _vp, _vp, _d, _i, _sz, _vp],

@@ -128,6 +128,22 @@ struct LensSlot {
     bool ev_overflow;     // more streams than events have used the slot: an eviction falls back to a device synchronise
 };
 
+// Fixed-point form of one pair of separable stretch maps (gf_undistort_rotate_superview_u8c3), cached like a lens table:
+// colq[w] = cvRound(32 mapx_row), then tcol[tiles_x + 1].  One slot per context: a render uses one stretch configuration.
+constexpr int STRETCH_MAX_INTS = 32768 + 1024;
+struct StretchSlot {
+    bool valid;
+    int w, h, mid_w;
+    float* key;           // host copy of mapx_row (w floats) and mapy_col (h floats) the slot was built from
+    int* dev;             // STRETCH_MAX_INTS ints
+    int* host;            // pinned staging
+    int c0row, fy;
+    hipEvent_t ev[LENS_EVENTS];
+    hipStream_t ev_stream[LENS_EVENTS];
+    bool ev_used[LENS_EVENTS];
+    bool ev_overflow;
+};
+
 struct Ctx {
     int device;
     int n_cu;             // compute units of the device (sizes the persistent grid of the fused kernel)
@@ -135,6 +151,7 @@ struct Ctx {
     int16_t* cubic_tab;   // device, 1024*16 int16 (cv2 INTER_CUBIC Q15 table)
     double* rp_tab;       // device, RP_TAB_DOUBLES doubles (build_rp_table)
     LensSlot lens[LENS_SLOTS];
+    StretchSlot stretch;
     unsigned long long tick;
     std::mutex mu;
 };
@@ -1010,6 +1027,17 @@ __device__ __forceinline__ void rp_nodes(const Xf& xf, const LensK& lk, const do
 }
 
 // Coefficient a of tile rows r0, r0 + rstride, ... (nr of them) from the node rows' coefficients: C[r][a] = sum_m Ly[r][m] C2[m][a].
+// One coefficient of one tile row: the node rows' coefficients c2[0..7] weighted with the row's Lagrange weights (this order).
+__device__ __forceinline__ double rp_row_coef(const double* c2, const double* ly_row)
+{
+    const double2* w = (const double2*)ly_row;
+    const double2 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
+    double cf = w0.x*c2[0];
+    cf = __fma_rn(w0.y, c2[1], cf); cf = __fma_rn(w1.x, c2[2], cf); cf = __fma_rn(w1.y, c2[3], cf);
+    cf = __fma_rn(w2.x, c2[4], cf); cf = __fma_rn(w2.y, c2[5], cf); cf = __fma_rn(w3.x, c2[6], cf); cf = __fma_rn(w3.y, c2[7], cf);
+    return cf;
+}
+
 __device__ __forceinline__ void rp_rows(const double (*C2)[RP_N], const RpConst& K, int a, int r0, int rstride, int nr, double (*C)[RP_N])
 {
     double c2[RP_N];
@@ -1018,12 +1046,7 @@ __device__ __forceinline__ void rp_rows(const double (*C2)[RP_N], const RpConst&
 #pragma unroll 2
     for (int j = 0; j < nr; j++) {
         const int r = r0 + j*rstride;
-        const double2* w = (const double2*)K.Ly[r];
-        const double2 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3];
-        double cf = w0.x*c2[0];
-        cf = __fma_rn(w0.y, c2[1], cf); cf = __fma_rn(w1.x, c2[2], cf); cf = __fma_rn(w1.y, c2[3], cf);
-        cf = __fma_rn(w2.x, c2[4], cf); cf = __fma_rn(w2.y, c2[5], cf); cf = __fma_rn(w3.x, c2[6], cf); cf = __fma_rn(w3.y, c2[7], cf);
-        C[r][a] = cf;
+        C[r][a] = rp_row_coef(c2, K.Ly[r]);
     }
 }
 
@@ -1976,6 +1999,193 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
     }
 }
 
+// K1s: fused remap + superview stretch (BASELINE config C4): gf_undistort_rotate_c3 followed by gf_superview_cubic_u8c3 without
+// the intermediate frame ever reaching HBM.  The reference rounds to uint8 between the two resampling steps
+// (stabilizer.py:1442 then nonlinear_stretch.py:130), so the intermediate image must exist -- here one tile of it at a time,
+// in LDS.
+// Work item = (frame, 64 x 64 tile of the INTERMEDIATE image, i.e. one tile of the RP grid).  The item owns the output
+// pixels whose bicubic window starts in that tile: output columns [tcol[tx], tcol[tx+1]) (the horizontal map is monotone;
+// host-built table) and, because the vertical map is a unit-step shift (sy = y + c0row, one fraction fy for all rows --
+// checked on the host), output rows [64 ty - c0row, 64 ty + 64 - c0row).  Their 4 x 4 windows reach one pixel to the left /
+// above the tile and two to the right / below, so the item computes the intermediate region
+//   rows 64 ty - 1 .. 64 ty + 65,  columns 64 tx - 4 .. 64 tx + 67   (67 rows of 18 four-pixel groups)
+// with exactly the code and the per-tile polynomials of k_undistort_rotate_rp -- the fringe pixels with the polynomials of
+// the eight neighbouring tiles they belong to, so that every intermediate pixel has the bits the stand-alone kernel gives
+// it -- packs it into LDS (pixels outside the intermediate image are 0, which is what BORDER_CONSTANT 0 of the stretch
+// step reads there) and then walks down its output columns as k_superview_cubic does, reading the window rows from LDS.
+// Steps per item, one workgroup barrier each: node values of the (up to) nine tiles -> row coefficients of the region's
+// rows -> the region's pixels -> the output pixels.
+constexpr int FS_QUADS = RT/PXT + 2;              // four-pixel groups per region row: 1 + 16 + 1
+constexpr int FS_ROWS = RT + 3;                   // region rows: 1 + 64 + 2
+constexpr int FS_PITCH = FS_QUADS*PXT*3;          // bytes per region row in LDS (216)
+struct FsShared {
+    RpConst K;                                    // 4.6 KB
+    double U[BLOCK/64][RP_N][RP_N];               // rp_nodes scratch, one per wave
+    double C2[9][RP_N][RP_N];                     // node-row coefficients of the 3 x 3 tiles around (tx, ty)
+    double C[3][FS_ROWS][RP_N];                   // [tile column part][region row]: row coefficients
+    int ok[12];                                   // per tile of the 3 x 3: 1 = polynomials, 0 = per-pixel path, -1 = no such tile
+    uint32_t I[FS_ROWS][FS_PITCH/4];              // the intermediate region, packed BGR bytes (14.5 KB)
+};
+static_assert(sizeof(FsShared) <= 40*1024, "four workgroups per CU");
+
+struct FsOut {                                    // the final (stretched) frames
+    uint8_t* dst; int w, h; size_t step, frame; int vec_ok;
+    const int* colq;                              // [w]  cvRound(32 * mapx_row[x])
+    const int* tcol;                              // [tiles_x + 1] first output column of every intermediate tile column
+    int c0row;                                    // sy = y + c0row  (integer part of the vertical map, minus nothing: window rows are sy-1 .. sy+2)
+    int fy;                                       // the vertical fraction (same for every row)
+};
+
+template <int BORDER>
+__global__ void __launch_bounds__(BLOCK, 4) k_undistort_rotate_superview(RemapArgs A, FsOut F, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                                        const double* __restrict__ rp_tab, const int16_t* __restrict__ ctab,
+                                                                        unsigned tiles_pad, unsigned n_work)
+{
+    constexpr int DEPTH = GF_DEPTH_U8;
+    __shared__ FsShared S;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    rp_load_consts(rp_tab, S.K, tid, BLOCK);
+    const double offx = rp_node_off(rp_tab, lane & 7), offy = rp_node_off(rp_tab, lane >> 3);
+    const double2* tab = (const double2*)lens;                  // lens table read from global memory (L2): nine lookups per item
+    __syncthreads();
+#pragma unroll 1
+    for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+        const unsigned frame = v / tiles_pad;
+        int tx, ty;
+        if (!tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty)) continue;          // uniform
+        const Xf& xf = xfs[frame];
+        const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+
+        // ---- 1. node values -> node-row coefficients of the 3 x 3 tiles (wave w: tiles w, w + 4, w + 8)
+#pragma unroll 1
+        for (int t9 = wave; t9 < 9; t9 += BLOCK/64) {
+            const int ntx = tx + t9 % 3 - 1, nty = ty + t9/3 - 1;
+            if (ntx < 0 || ntx >= A.tiles_x || nty < 0 || nty >= A.tiles_y) { if (lane == 0) S.ok[t9] = -1; continue; }
+            rp_nodes<false>(xf, lk, tab, offx, offy, lane & 7, lane >> 3, ntx, nty, S.U[wave], S.K, S.C2[t9], &S.ok[t9], nullptr);
+            asm volatile("" ::: "memory");
+        }
+        lds_barrier();
+
+        // ---- 2. row coefficients of the region's rows, for the three tile columns
+#pragma unroll 1
+        for (int o = tid; o < 3*FS_ROWS*RP_N; o += BLOCK) {
+            const int a = o & (RP_N - 1), rr = (o >> 3) % FS_ROWS, part_x = (o >> 3)/FS_ROWS;
+            const int part_y = rr == 0 ? 0 : rr <= RT ? 1 : 2;
+            const int lr = rr == 0 ? RT - 1 : rr <= RT ? rr - 1 : rr - RT - 1;        // row of that tile
+            const int t9 = part_y*3 + part_x;
+            if (S.ok[t9] == 1) {
+                double c2[RP_N];
+#pragma unroll
+                for (int m = 0; m < RP_N; m++) c2[m] = S.C2[t9][m][a];
+                S.C[part_x][rr][a] = rp_row_coef(c2, S.K.Ly[lr]);
+            }
+        }
+        lds_barrier();
+
+        // ---- 3. the intermediate region: the pixels of k_undistort_rotate_rp, packed into LDS
+        {
+            const RpFrameC fc = rp_frame_consts(xf);
+#pragma unroll 1
+            for (int p = tid; p < FS_QUADS*FS_ROWS; p += BLOCK) {
+                const int rr = p/FS_QUADS, q = p - rr*FS_QUADS;
+                const int part_x = q == 0 ? 0 : q <= RT/PXT ? 1 : 2, part_y = rr == 0 ? 0 : rr <= RT ? 1 : 2;
+                const int okt = S.ok[part_y*3 + part_x];
+                const int x0 = tx*RT - PXT + q*PXT, y = ty*RT - 1 + rr;
+                uint32_t w0 = 0, w1 = 0, w2 = 0;
+                if (okt >= 0 && y >= 0 && y < A.dh && x0 + PXT > 0 && x0 < A.dw) {
+                    const int lxq = (q - 1) & (RT_TPR - 1);              // the group's place in its own tile
+                    double z[PXT];
+#pragma unroll
+                    for (int e = 0; e < PXT; e++) z[e] = ((double)(lxq*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);
+                    int iu[PXT], iv[PXT], px[PXT][3];
+                    if (okt == 1) rp_coords(rp_row_consts(fc, y), S.C[part_x][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+                    else coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), tab, x0, iu, iv);
+                    (void)remap4<DEPTH, BORDER, true>(s, iu, iv, A.cval, px);
+                    if (x0 < 0 || x0 + PXT > A.dw) {                     // columns outside the intermediate image read as 0
+#pragma unroll
+                        for (int e = 0; e < PXT; e++)
+                            if (x0 + e < 0 || x0 + e >= A.dw) px[e][0] = px[e][1] = px[e][2] = 0;
+                    }
+                    w0 = pack4_hi16(px[0][0], px[0][1], px[0][2], px[1][0]);
+                    w1 = pack4_hi16(px[1][1], px[1][2], px[2][0], px[2][1]);
+                    w2 = pack4_hi16(px[2][2], px[3][0], px[3][1], px[3][2]);
+                }
+                uint32_t* d = &S.I[rr][q*3];
+                d[0] = w0; d[1] = w1; d[2] = w2;
+            }
+        }
+        lds_barrier();
+
+        // ---- 4. the output pixels this item owns, column by column
+        {
+            const int Xa = F.tcol[tx], Xb = F.tcol[tx + 1];
+            const int Ya = ty == 0 ? 0 : min(max(ty*RT - F.c0row, 0), F.h);
+            const int Yb = ty == A.tiles_y - 1 ? F.h : min(max(ty*RT + RT - F.c0row, 0), F.h);
+            const int xorg = tx*RT - PXT, yorg = ty*RT - 1;             // region origin in the intermediate image
+#pragma unroll 1
+            for (int cb = Xa & ~3; cb < Xb && Ya < Yb; cb += BLOCK) {
+                const int wc4 = min(BLOCK, (Xb - cb + 3) & ~3);          // columns of this chunk, a multiple of 4
+                const int nseg = BLOCK/wc4;
+                const int seglen = (Yb - Ya + nseg - 1)/nseg;
+                const int seg = tid/wc4, col = tid - seg*wc4;
+                const int X = cb + col;
+                const bool col_ok = seg < nseg && X >= Xa && X < Xb;
+                const int y0 = Ya + seg*seglen, y1 = col_ok ? min(Yb, y0 + seglen) : y0;
+                const int isx = F.colq[min(max(X, 0), F.w - 1)];
+                const int sx = sat_s16(isx >> INTER_BITS) - 1, fx = isx & 31;
+                const int cidx = sx - xorg;
+                const bool in_x = cidx >= 0 && cidx + 3 < FS_QUADS*PXT;   // otherwise the window lies outside the image: 0
+                const unsigned bo = in_x ? (unsigned)cidx*3u : 0u;
+                const int e = (F.fy*32 + fx)*2;
+                const uint4 wq0 = ((const uint4*)ctab)[e], wq1 = ((const uint4*)ctab)[e + 1];
+                // lanes 4q..4q+3 hold four consecutive columns of one row (cb and wc4 are multiples of 4): 12 contiguous bytes
+                const bool quad_full = F.vec_ok && ((__ballot(col_ok) >> (lane & ~3)) & 0xFull) == 0xFull;
+                auto load_row = [&](int r) -> SvRow {                   // region row r (may be outside: zeros)
+                    SvRaw raw; raw.a = raw.b = raw.c = 0;
+                    if (in_x && r >= 0 && r < FS_ROWS) {
+                        const uint32_t* pr = &S.I[r][bo >> 2];
+                        const uint32_t d0 = pr[0], d1 = pr[1], d2 = pr[2], d3 = (bo >> 2) + 3 < FS_PITCH/4 ? pr[3] : 0u;
+                        raw.a = __builtin_amdgcn_alignbyte(d1, d0, bo); raw.b = __builtin_amdgcn_alignbyte(d2, d1, bo); raw.c = __builtin_amdgcn_alignbyte(d3, d2, bo);
+                    }
+                    return sv_unpack(raw);
+                };
+                auto store = [&](int y, uint32_t px) {
+                    const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);     // quad_perm [1,2,3,3]
+                    uint8_t* D = F.dst + (size_t)frame*F.frame + (size_t)y*F.step + (size_t)X*3;
+                    if (quad_full) {
+                        const int j = lane & 3;
+                        if (j < 3) *(uint32_t*)(D + j) = __builtin_amdgcn_alignbit(nb, px << 8, 8u + 8u*(unsigned)j);
+                    } else if (col_ok) {
+                        D[0] = (uint8_t)px; D[1] = (uint8_t)(px >> 8); D[2] = (uint8_t)(px >> 16);
+                    }
+                };
+                if (y0 < y1) {
+                    int r = y0 + F.c0row - 1 - yorg;                      // region row of the first window row of output row y0
+                    SvRow R[SV_G + 3];
+                    R[0] = load_row(r); R[1] = load_row(r + 1); R[2] = load_row(r + 2);
+                    int y = y0;
+#pragma unroll 1
+                    for (; y + SV_G <= y1; y += SV_G, r += SV_G) {
+#pragma unroll
+                        for (int k = 0; k < SV_G; k++) R[3 + k] = load_row(r + 3 + k);
+#pragma unroll
+                        for (int k = 0; k < SV_G; k++) store(y + k, in_x ? sv_pixel(R[k], R[k + 1], R[k + 2], R[k + 3], wq0, wq1) : 0u);
+#pragma unroll
+                        for (int k = 0; k < 3; k++) R[k] = R[SV_G + k];
+                    }
+#pragma unroll 1
+                    for (; y < y1; y++, r++) {
+                        R[3] = load_row(r + 3);
+                        store(y, in_x ? sv_pixel(R[0], R[1], R[2], R[3], wq0, wq1) : 0u);
+                        R[0] = R[1]; R[1] = R[2]; R[2] = R[3];
+                    }
+                }
+            }
+        }
+        lds_barrier();          // the region and the coefficient buffers are reused by the next item
+    }
+}
+
 // K6: hyperlapse blend passes (unfused form).
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_blend_acc(const T* __restrict__ f, double* acc, double wgt, int reset, size_t n)
@@ -2123,16 +2333,21 @@ struct LensLease {
     LensLease(Ctx* ctx, hipStream_t st) : c(ctx), stream(st), slot(-1), lock(ctx->mu) {}
     int mode() const { return c->k1_mode; }
     int acquire(const double* D, const double** dev, LensK* lk);
-    ~LensLease()
+    bool stretch_used = false;
+    int acquire_stretch(const float* mapx, const float* mapy, int w, int h, int mid_w, int mid_h, const int** colq, const int** tcol, int* c0row, int* fy);
+    template <class Slot> void mark(Slot& s)
     {
-        if (slot < 0) return;
-        LensSlot& s = c->lens[slot];
         int e = -1;
         for (int i = 0; i < LENS_EVENTS; i++) if (s.ev_used[i] && s.ev_stream[i] == stream) { e = i; break; }
         if (e < 0) for (int i = 0; i < LENS_EVENTS; i++) if (!s.ev_used[i]) { e = i; break; }
         if (e < 0) { s.ev_overflow = true; return; }
         if (hipEventRecord(s.ev[e], stream) == hipSuccess) { s.ev_used[e] = true; s.ev_stream[e] = stream; }
         else s.ev_overflow = true;
+    }
+    ~LensLease()
+    {
+        if (slot >= 0) mark(c->lens[slot]);
+        if (stretch_used) mark(c->stretch);
     }
 };
 
@@ -2172,6 +2387,63 @@ int LensLease::acquire(const double* D, const double** dev, LensK* lk)
     memcpy(s.D, D, sizeof s.D);
     s.valid = true; s.last_use = c->tick;
     *dev = s.dev; slot = victim;
+    return GF_OK;
+}
+
+// The fixed-point stretch tables for (mapx_row, mapy_col): GF_ERR_UNSUPPORTED unless the vertical map is a unit-step shift
+// (row y reads source rows y + c .. y + c + 3 with one fraction for all rows: what NonlinearStretch produces when the
+// output height equals the input height) and the horizontal map is monotone -- the fused kernel's work split rests on both.
+int LensLease::acquire_stretch(const float* mapx, const float* mapy, int w, int h, int mid_w, int mid_h, const int** colq, const int** tcol, int* c0row, int* fy)
+{
+    (void)mid_h;
+    StretchSlot& s = c->stretch;
+    const int tiles_x = (mid_w + RT - 1)/RT;
+    if (w + tiles_x + 1 > STRETCH_MAX_INTS) return fail(GF_ERR_UNSUPPORTED, "%s: stretch maps too large (%lld columns)", "gf_undistort_rotate_superview_u8c3", w);
+    const bool hit = s.valid && s.w == w && s.h == h && s.mid_w == mid_w && memcmp(s.key, mapx, sizeof(float)*(size_t)w) == 0 &&
+                     memcmp(s.key + w, mapy, sizeof(float)*(size_t)h) == 0;
+    if (!hit) {
+        // rows: cvRound(32 my) = 32 y + q0 for every y
+        const auto q5 = [](float v) -> long long { const float t = v*32.f; if (!(t == t) || fabsf(t) >= 1048576.f) return LLONG_MIN; return (long long)lrintf(t); };
+        const long long q0 = q5(mapy[0]);
+        if (q0 == LLONG_MIN) return fail(GF_ERR_UNSUPPORTED, "%s: vertical map out of range", "gf_undistort_rotate_superview_u8c3");
+        for (int y = 1; y < h; y++)
+            if (q5(mapy[y]) != q0 + 32ll*y) return fail(GF_ERR_UNSUPPORTED, "%s: the vertical map is not a unit-step shift (row %lld): use the two calls", "gf_undistort_rotate_superview_u8c3", y);
+        if (s.valid) {
+            s.valid = false;
+            if (s.ev_overflow) HIP_TRY(hipDeviceSynchronize());
+            for (int i = 0; i < LENS_EVENTS; i++) if (s.ev_used[i]) HIP_TRY(hipEventSynchronize(s.ev[i]));
+        }
+        for (int i = 0; i < LENS_EVENTS; i++) s.ev_used[i] = false;
+        s.ev_overflow = false;
+        int* H = s.host;
+        long long prev = LLONG_MIN;
+        for (int x = 0; x < w; x++) {
+            const long long q = q5(mapx[x]);
+            if (q == LLONG_MIN || q < prev) return fail(GF_ERR_UNSUPPORTED, "%s: the horizontal map is not monotone (column %lld): use the two calls", "gf_undistort_rotate_superview_u8c3", x);
+            prev = q; H[x] = (int)q;
+        }
+        // owner tile column of an output column: the tile of its second tap column (the window is sx1 - 1 .. sx1 + 2), clamped
+        int* T = H + w;
+        int x = 0;
+        for (int k = 0; k <= tiles_x; k++) {
+            while (x < w) {
+                const int sx1 = (H[x] >> INTER_BITS) < -32768 ? -32768 : (H[x] >> INTER_BITS) > 32767 ? 32767 : (H[x] >> INTER_BITS);
+                int owner = sx1 < 0 ? 0 : sx1/RT;
+                if (owner > tiles_x - 1) owner = tiles_x - 1;
+                if (owner >= k) break;
+                x++;
+            }
+            T[k] = k == tiles_x ? w : x;
+        }
+        HIP_TRY(hipMemcpyAsync(s.dev, H, sizeof(int)*(size_t)(w + tiles_x + 1), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        memcpy(s.key, mapx, sizeof(float)*(size_t)w); memcpy(s.key + w, mapy, sizeof(float)*(size_t)h);
+        s.w = w; s.h = h; s.mid_w = mid_w;
+        s.c0row = (int)(q0 >> INTER_BITS); s.fy = (int)(q0 & 31);
+        s.valid = true;
+    }
+    *colq = s.dev; *tcol = s.dev + w; *c0row = s.c0row; *fy = s.fy;
+    stretch_used = true;
     return GF_OK;
 }
 
@@ -2244,6 +2516,16 @@ GF_API int gf_ctx_create(int device, void** ctx)
         build_rp_table(t);
         e = hipMemcpy(c->rp_tab, t, sizeof t, hipMemcpyHostToDevice);
     }
+    {
+        StretchSlot& t = c->stretch;
+        t.valid = false; t.key = nullptr; t.dev = nullptr; t.host = nullptr; t.ev_overflow = false; t.w = t.h = t.mid_w = 0; t.c0row = t.fy = 0;
+        for (int k = 0; k < LENS_EVENTS; k++) { t.ev[k] = nullptr; t.ev_used[k] = false; t.ev_stream[k] = nullptr; }
+        t.key = new (std::nothrow) float[2*32768];
+        if (!t.key) e = hipErrorOutOfMemory;
+        if (e == hipSuccess) e = hipMalloc((void**)&t.dev, STRETCH_MAX_INTS*sizeof(int));
+        if (e == hipSuccess) e = hipHostMalloc((void**)&t.host, STRETCH_MAX_INTS*sizeof(int), hipHostMallocDefault);
+        for (int k = 0; k < LENS_EVENTS && e == hipSuccess; k++) e = hipEventCreateWithFlags(&t.ev[k], hipEventDisableTiming);
+    }
     for (int i = 0; i < LENS_SLOTS && e == hipSuccess; i++) {
         e = hipMalloc((void**)&c->lens[i].dev, LENS_DOUBLES*sizeof(double));
         if (e == hipSuccess) e = hipHostMalloc((void**)&c->lens[i].host, LENS_DOUBLES*sizeof(double), hipHostMallocDefault);
@@ -2273,6 +2555,10 @@ GF_API int gf_ctx_destroy(void* ctx)
     DeviceGuard dg(c->device);
     if (c->cubic_tab) (void)hipFree(c->cubic_tab);
     if (c->rp_tab) (void)hipFree(c->rp_tab);
+    delete[] c->stretch.key;
+    if (c->stretch.dev) (void)hipFree(c->stretch.dev);
+    if (c->stretch.host) (void)hipHostFree(c->stretch.host);
+    for (int k = 0; k < LENS_EVENTS; k++) if (c->stretch.ev[k]) (void)hipEventDestroy(c->stretch.ev[k]);
     for (int i = 0; i < LENS_SLOTS; i++) {
         if (c->lens[i].dev) (void)hipFree(c->lens[i].dev);
         if (c->lens[i].host) (void)hipHostFree(c->lens[i].host);
@@ -2530,6 +2816,46 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
     return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
                         border, bv, (hipStream_t)stream);
+}
+
+GF_API int gf_undistort_rotate_superview_u8c3(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep, size_t sframe,
+                                              int mid_w, int mid_h,
+                                              uint8_t* dst, int dw, int dh, size_t dstep, size_t dframe,
+                                              const double D[4], const gf_frame_xform* xf_dev, int n_frames,
+                                              const float* mapx_row_host, const float* mapy_col_host,
+                                              int border, const double bv[4], gf_stream_t stream)
+{
+    const char* fn = "gf_undistort_rotate_superview_u8c3";
+    int rc = fused_checks(fn, ctx, GF_DEPTH_U8, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_frames, n_frames, border);
+    if (rc) return rc;
+    if (border == GF_BORDER_TRANSPARENT) return fail(GF_ERR_UNSUPPORTED, "%s: BORDER_TRANSPARENT needs the previous intermediate frame; use the two calls", fn);
+    if (mid_w <= 0 || mid_h <= 0 || mid_w >= SHRT_MAX || mid_h >= SHRT_MAX) return fail(GF_ERR_INVALID_ARG, "%s: bad intermediate size, w=%lld", fn, mid_w);
+    if (!mapx_row_host || !mapy_col_host) return fail(GF_ERR_INVALID_ARG, "%s: null map", fn);
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", fn);
+    const double* lens; LensK lk;
+    LensLease lease(c, (hipStream_t)stream);
+    rc = lease.acquire(D, &lens, &lk); if (rc) return rc;
+    FsOut F;
+    rc = lease.acquire_stretch(mapx_row_host, mapy_col_host, dw, dh, mid_w, mid_h, &F.colq, &F.tcol, &F.c0row, &F.fy); if (rc) return rc;
+    F.dst = dst; F.w = dw; F.h = dh; F.step = dstep; F.frame = dframe;
+    F.vec_ok = (((uintptr_t)dst | dstep | dframe) & 3) == 0 ? 1 : 0;
+    RemapArgs A = make_args(GF_DEPTH_U8, src, sw, sh, sstep, sframe, nullptr, mid_w, mid_h, 0, 0, bv);
+    A.tiles_x = (mid_w + RT - 1)/RT; A.tiles_y = (mid_h + RT - 1)/RT;
+    const unsigned tiles_pad = ((unsigned)(A.tiles_x*A.tiles_y) + NXCD - 1) & ~(unsigned)(NXCD - 1);
+    const unsigned long long n_work = (unsigned long long)tiles_pad*(unsigned)n_frames;
+    if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many tiles in one call (%lld)", fn, (long long)n_work);
+    static const unsigned fs_wg_per_cu = []{ const char* e = getenv("GF_FS_WG_PER_CU"); int v = e ? atoi(e) : 0; return (unsigned)(v > 0 && v <= 64 ? v : 16); }();
+    unsigned blocks = (unsigned)c->n_cu*fs_wg_per_cu & ~(unsigned)(NXCD - 1);
+    if (blocks == 0) blocks = NXCD;
+    if (blocks > n_work) blocks = (unsigned)n_work;
+    if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_superview<GF_BORDER_CONSTANT>), dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, A, F, (const Xf*)xf_dev, lens, lk,
+                                                         (const double*)c->rp_tab, (const int16_t*)c->cubic_tab, tiles_pad, (unsigned)n_work);
+    else                              hipLaunchKernelGGL((k_undistort_rotate_superview<GF_BORDER_REPLICATE>), dim3(blocks), dim3(BLOCK), 0, (hipStream_t)stream, A, F, (const Xf*)xf_dev, lens, lk,
+                                                         (const double*)c->rp_tab, (const int16_t*)c->cubic_tab, tiles_pad, (unsigned)n_work);
+    HIP_TRY(hipGetLastError());
+    return GF_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

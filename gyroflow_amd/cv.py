@@ -282,6 +282,46 @@ def superview_cubic(src, mapx_row, mapy_col, dst=None, borderMode=BORDER_CONSTAN
     return d if (src.dim() == 4) else d[0]
 
 
+def undistort_rotate_superview(src, D, xforms_dev, mid_size, mapx_row, mapy_col, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+    """undistort_rotate() to an intermediate frame of mid_size followed by superview_cubic() (NonlinearStretch.apply_stretch on
+    the remapped frame: stabilizer.py:1442 then nonlinear_stretch.py:130), in one launch whose intermediate frame stays in LDS.
+    src: CUDA uint8 [N,H,W,3]; mapx_row / mapy_col: float32 vectors of the output width / height (numpy, or tensors that
+    are copied to the host once).  Maps the fused kernel cannot take (vertical scale != 1, non-monotone) run as the two
+    launches.  Returns dst [N, len(mapy_col), len(mapx_row), 3]."""
+    if not (isinstance(src, torch.Tensor) and src.is_cuda):
+        raise TypeError("undistort_rotate_superview works on CUDA tensors")
+    dev = src.device
+    s = _frames4(src, "src")
+    if s.dtype != torch.uint8:
+        raise TypeError("the superview stretch (INTER_CUBIC) is implemented for uint8 only")
+    n = s.shape[0]
+    if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
+        raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,13] tensor with N = number of frames")
+    mx = np.ascontiguousarray(mapx_row.detach().cpu().numpy() if isinstance(mapx_row, torch.Tensor) else mapx_row, dtype=np.float32).reshape(-1)
+    my = np.ascontiguousarray(mapy_col.detach().cpu().numpy() if isinstance(mapy_col, torch.Tensor) else mapy_col, dtype=np.float32).reshape(-1)
+    dw, dh = mx.size, my.size
+    mw, mh = int(mid_size[0]), int(mid_size[1])
+    if dst is None:
+        d = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=dev)
+    else:
+        d = _frames4(dst, "dst")
+        if tuple(d.shape) != (n, dh, dw, 3) or d.dtype != torch.uint8 or d.device != dev:
+            raise ValueError("dst has the wrong shape/dtype/device")
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        rc = lib.gf_undistort_rotate_superview_u8c3(ctx, _ptr(s), s.shape[2], s.shape[1], s.stride(1), s.stride(0), mw, mh,
+                                                    _ptr(d), dw, dh, d.stride(1), d.stride(0), _lib.distortion(D), _ptr(xforms_dev), n,
+                                                    mx.ctypes.data_as(_vp), my.ctypes.data_as(_vp), int(borderMode),
+                                                    _lib.border_value(borderValue), _stream(dev))
+        if rc == _lib.GF_ERR_UNSUPPORTED and borderMode != BORDER_TRANSPARENT:
+            # maps outside the fused kernel's envelope: the same result from the two launches
+            mid = undistort_rotate(s, D, xforms_dev, (mw, mh), borderMode=borderMode, borderValue=borderValue)
+            superview_cubic(mid, torch.from_numpy(mx).to(dev), torch.from_numpy(my).to(dev), dst=d)
+        else:
+            _lib.check(rc)
+    return d if (src.dim() == 4) else d[0]
+
+
 def blend_accumulate(frame, acc, weight, reset):
     """acc (CUDA float64, same number of elements as frame) = (acc*0 if reset else acc) + weight*frame."""
     dev = frame.device

@@ -152,6 +152,24 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
                            const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
                            int border, const double border_value_host[4], gf_stream_t stream);
 
+/* BASELINE config C4 in one launch: gf_undistort_rotate_c3 (u8) into an intermediate image of mid_w x mid_h, then
+ * gf_superview_cubic_u8c3 (BORDER_CONSTANT 0, as NonlinearStretch.apply_stretch calls cv2.remap) to dst -- with the
+ * intermediate image living tile by tile in LDS instead of HBM
+ *   replaces stabilizer.py:1423-1443 followed by nonlinear_stretch.py:130 on the frame it produced.
+ * Output is bit-identical to the two calls (the uint8 rounding between the two resampling steps is kept).
+ * mapx_row_host / mapy_col_host: HOST arrays of dw / dh floats (map1[0, :] and map2[:, 0] of recompute_maps,
+ * nonlinear_stretch.py:58-100); their fixed-point form is cached on the device per context (the first call with new maps
+ * waits for a small upload).  `border` / border_value_host apply to the remap step.  GF_ERR_UNSUPPORTED (use the two calls)
+ * unless the vertical map is a unit-step shift -- output row y reads intermediate rows y + c .. y + c + 3 with one fraction
+ * for all rows, which is what recompute_maps gives when the output height equals the intermediate height -- and the
+ * horizontal map is monotone; GF_BORDER_TRANSPARENT is unsupported as well. */
+GF_API int gf_undistort_rotate_superview_u8c3(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                                       int mid_w, int mid_h,
+                                       uint8_t* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                                       const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
+                                       const float* mapx_row_host, const float* mapy_col_host,
+                                       int border, const double border_value_host[4], gf_stream_t stream);
+
 /* gf_undistort_rotate_c3 for callers that cannot allocate: code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc.  (No counterpart in the reference.)  Same arithmetic, same kernels and bit-identical output, but no
  * context: the device memory the kernel needs beyond src and dst (lens table, RP table, the batch's transforms: 28 KB)

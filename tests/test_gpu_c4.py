@@ -87,3 +87,72 @@ def test_c4_chain_small_vs_oracle(gpu, orc):
         want_mid = orc.remap_linear(frames[i], o1, o2)
         np.testing.assert_array_equal(mid[i].cpu().numpy(), want_mid)
         np.testing.assert_array_equal(out[i], orc.remap_cubic(want_mid, ns.map1, ns.map2))
+
+
+@pytest.mark.parametrize("border", [0, 1])
+def test_c4_fused_equals_two_launches_small(gpu, orc, border):
+    """The one-launch chain against the two launches and against the oracle chain, 500x375 -> 360x270 -> 480x270 (tiles of
+    every kind: interior, all four edges, partial last tile row / column)."""
+    from gyroflow_amd import cv
+    cal, frames, q, ns, (w, h), (ow, oh), fsz = _small_c4(gpu, n=3)
+    src = torch.from_numpy(frames).to(gpu)
+    xf = cv.xforms_to_device(cal.frame_xforms(1.0, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
+    mid = cv.undistort_rotate(src, cal.D, xf, (ow, oh), borderMode=border, borderValue=(7, 8, 9))
+    two = ns.apply_stretch_batch(mid)
+    one = cv.undistort_rotate_superview(src, cal.D, xf, (ow, oh), ns.map1[0], ns.map2[:, 0], borderMode=border, borderValue=(7, 8, 9))
+    assert one.shape == two.shape
+    bad = (one != two).any(dim=-1)
+    assert not bool(bad.any()), "fused chain differs from the two launches at %s" % (torch.nonzero(bad)[:5].tolist(),)
+    K, D, R, P, od = cal._frame_matrices(1.0, (ow, oh), (w, h), q[1], None, True)
+    o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, od, orc.CV_16SC2)
+    want = orc.remap_cubic(orc.remap_linear(frames[1], o1, o2, borderMode=border, borderValue=(7, 8, 9)), ns.map1, ns.map2)
+    np.testing.assert_array_equal(one[1].cpu().numpy(), want)
+
+
+def test_c4_fused_equals_two_launches_full_size(gpu):
+    """C4 itself: 4000x3000 -> 2880x2160 -> 3840x2160 with the reference's own stretch maps, two frames of the real trace; padded
+    output rows (pitch not a multiple of 4: byte stores) and packed rows."""
+    from gyroflow_amd import FisheyeCalibrator, synthetic_frames, cv
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero9_4k_43"))
+    w, h, ow, oh = 4000, 3000, 2880, 2160
+    mx, my = _c4_maps()
+    q = _trace(2, start=700)
+    frames = torch.from_numpy(np.stack(synthetic_frames(w, h, n=2, seed=47))).to(gpu)
+    xf = cv.xforms_to_device(cal.frame_xforms(1.0, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
+    mid = cv.undistort_rotate(frames, cal.D, xf, (ow, oh))
+    two = cv.superview_cubic(mid, torch.from_numpy(mx).to(gpu), torch.from_numpy(my).to(gpu))
+    one = cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my)
+    assert torch.equal(one, two)
+    big = torch.full((2, 2160, 3841, 3), 55, dtype=torch.uint8, device=gpu)
+    cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my, dst=big[:, :, :3840])
+    assert torch.equal(big[:, :, :3840], two) and int((big[:, :, 3840] != 55).sum()) == 0
+
+
+def test_c4_fused_other_maps_and_fallback(gpu):
+    """Other stretch settings (safe area, exponent: other column ownership tables), a second call with other maps on the same
+    context (the cached table is replaced), and maps outside the fused kernel's envelope (vertical scale != 1), which the
+    Python call routes through the two launches."""
+    from gyroflow_amd import cv, NonlinearStretch, _lib
+    import ctypes as C
+    cal, frames, q, ns0, (w, h), (ow, oh), fsz = _small_c4(gpu, n=2)
+    src = torch.from_numpy(frames).to(gpu)
+    xf = cv.xforms_to_device(cal.frame_xforms(1.0, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
+    mid = cv.undistort_rotate(src, cal.D, xf, (ow, oh))
+    for out_size, safe, expo in (((480, 270), 0.3, 1.7), ((640, 270), 0.0, 3.0), ((480, 270), 0.999, 2.0), ((400, 270), 0.0, 2.0), ((512, 288), 0.1, 2.0)):
+        ns = NonlinearStretch((ow, oh), out_size, safe_area=0, expo=expo)
+        ns.set_safe_area(safe)
+        ns.recompute_maps()
+        two = ns.apply_stretch_batch(mid)
+        one = cv.undistort_rotate_superview(src, cal.D, xf, (ow, oh), ns.map1[0], ns.map2[:, 0])
+        assert torch.equal(one, two), (out_size, safe, expo)
+    # the C ABI itself refuses what the kernel cannot do
+    lib, ctx = _lib.load(), _lib.ctx(gpu.index or 0)
+    ns = NonlinearStretch((ow, oh), (512, 288)); ns.recompute_maps()
+    mx = np.ascontiguousarray(ns.map1[0]); my = np.ascontiguousarray(ns.map2[:, 0])
+    out = torch.empty((2, 288, 512, 3), dtype=torch.uint8, device=gpu)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    rc = lib.gf_undistort_rotate_superview_u8c3(ctx, p(src), w, h, w * 3, w * h * 3, ow, oh, p(out), 512, 288, 512 * 3, 512 * 288 * 3,
+                                                _lib.distortion(cal.D), p(xf), 2, mx.ctypes.data_as(C.c_void_p), my.ctypes.data_as(C.c_void_p), 0,
+                                                _lib.border_value(0), None)
+    assert rc == -3 and b"unit-step" in lib.gf_last_error()
