@@ -8,7 +8,7 @@ import numpy as np
 import torch  # noqa: F401  -- imported first so libgfremap.so binds to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgfremap.so")
+LIB_PATH = os.environ.get("GF_LIB_PATH") or os.path.join(_HERE, "libgfremap.so")     # GF_LIB_PATH: A/B builds of tools/ only
 
 GF_OK = 0
 GF_ERR_INVALID_ARG, GF_ERR_HIP, GF_ERR_UNSUPPORTED, GF_ERR_SINGULAR = -1, -2, -3, -4

@@ -2056,9 +2056,13 @@ __global__ void __launch_bounds__(BLOCK, 4) k_undistort_rotate_superview(RemapAr
         const Xf& xf = xfs[frame];
         const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
 
+#ifndef GF_FS_ABL
+#define GF_FS_ABL 0          /* tools/ ablation builds: bit 0 = centre tile's polynomials only, bit 1 = no region pixels, bit 2 = no output pixels */
+#endif
         // ---- 1. node values -> node-row coefficients of the 3 x 3 tiles (wave w: tiles w, w + 4, w + 8)
 #pragma unroll 1
         for (int t9 = wave; t9 < 9; t9 += BLOCK/64) {
+            if ((GF_FS_ABL & 1) && t9 != 4) { if (lane == 0) S.ok[t9] = -1; continue; }
             const int ntx = tx + t9 % 3 - 1, nty = ty + t9/3 - 1;
             if (ntx < 0 || ntx >= A.tiles_x || nty < 0 || nty >= A.tiles_y) { if (lane == 0) S.ok[t9] = -1; continue; }
             rp_nodes<false>(xf, lk, tab, offx, offy, lane & 7, lane >> 3, ntx, nty, S.U[wave], S.K, S.C2[t9], &S.ok[t9], nullptr);
@@ -2092,7 +2096,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_undistort_rotate_superview(RemapAr
                 const int okt = S.ok[part_y*3 + part_x];
                 const int x0 = tx*RT - PXT + q*PXT, y = ty*RT - 1 + rr;
                 uint32_t w0 = 0, w1 = 0, w2 = 0;
-                if (okt >= 0 && y >= 0 && y < A.dh && x0 + PXT > 0 && x0 < A.dw) {
+                if (!(GF_FS_ABL & 2) && okt >= 0 && y >= 0 && y < A.dh && x0 + PXT > 0 && x0 < A.dw) {
                     const int lxq = (q - 1) & (RT_TPR - 1);              // the group's place in its own tile
                     double z[PXT];
 #pragma unroll
@@ -2123,7 +2127,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_undistort_rotate_superview(RemapAr
             const int Yb = ty == A.tiles_y - 1 ? F.h : min(max(ty*RT + RT - F.c0row, 0), F.h);
             const int xorg = tx*RT - PXT, yorg = ty*RT - 1;             // region origin in the intermediate image
 #pragma unroll 1
-            for (int cb = Xa & ~3; cb < Xb && Ya < Yb; cb += BLOCK) {
+            for (int cb = Xa & ~3; cb < Xb && Ya < Yb && !(GF_FS_ABL & 4); cb += BLOCK) {
                 const int wc4 = min(BLOCK, (Xb - cb + 3) & ~3);          // columns of this chunk, a multiple of 4
                 const int nseg = BLOCK/wc4;
                 const int seglen = (Yb - Ya + nseg - 1)/nseg;
