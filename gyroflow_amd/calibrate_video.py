@@ -183,21 +183,27 @@ class FisheyeCalibrator:
         return cv.fisheye_initUndistortRectifyMap(scaled_K, D, R, new_K, out_dim, cv.CV_16SC2, device=device)
 
     # ------------------------------------------------------------------ fused-path parameters
+    def map_scale(self):
+        """The float32 map rescale of a stretched preset, (orig_w, calib_w, orig_h, calib_h) (calibrate_video.py:378), for
+        cv.undistort_rotate(map_scale=...); None for ordinary presets."""
+        if not self.image_is_stretched():
+            return None
+        return (self.orig_dimension[0], self.calib_dimension[0], self.orig_dimension[1], self.calib_dimension[1])
+
     def frame_xform(self, fov_scale=1.0, output_dim=None, new_img_dim=None, quat=None, focalCenter=None):
-        """One gf_frame_xform row (13 float64) for cv.undistort_rotate (which also takes self.D): same parameters as get_maps()."""
-        if self.image_is_stretched():
-            raise NotImplementedError("stretched presets go through get_maps() + remap() (float32 map rescale)")
+        """One gf_frame_xform row (13 float64) for cv.undistort_rotate (which also takes self.D): same parameters as get_maps().
+        For a stretched preset pass map_scale() to cv.undistort_rotate as well."""
         scaled_K, D, R, new_K, _ = self._frame_matrices(fov_scale, output_dim, new_img_dim, quat, focalCenter, True)
         return _lib.xform_to_array(_lib.make_frame_xform(scaled_K, R, new_K))
 
     def frame_xforms(self, fov_scales, quats, output_dim=None, new_img_dim=None, focalCenters=None):
         """[N,13] float64: frame_xform() for every (fov_scale[i], quat[i], focalCenter[i]), built in one pass: the same float64
         operations as _frame_matrices (calibrate_video.py:351-370), element-wise over the batch, then one C call."""
-        if self.image_is_stretched():
-            raise NotImplementedError("stretched presets go through get_maps() + remap() (float32 map rescale)")
         quats = np.asarray(quats, np.float64).reshape(-1, 4)
         n = quats.shape[0]
         fov = np.broadcast_to(np.asarray(fov_scales, np.float64), (n,))
+        if new_img_dim and self.image_is_stretched():          # new_img_dim is the size of the unstretched video frame (:341-343)
+            new_img_dim = self.get_stretched_size_from_dimension(new_img_dim)
         img_dim = new_img_dim if new_img_dim else self.calib_dimension
         out_dim = output_dim if output_dim else self.calib_dimension
         cd = self.calib_dimension

@@ -481,6 +481,31 @@ __device__ __forceinline__ void coord_q5x4(const RowC& r, const Xf& xf, const Le
     }
 }
 
+// Q5 integers of PXT adjacent pixels for a stretched preset: the float32 maps of k_fisheye_maps<false> (per-pixel table
+// coordinates, exact formula where the table does not apply), numpy's float32 rescale and cv::convertMaps of k_convert_maps,
+// then the CV_16SC2 map entry put back together as remap reads it -- the same values, pixel by pixel, as the three launches.
+__device__ __forceinline__ void coord_q5x4_stretched(const RowC& r, const Xf& xf, const LensK& lk, unsigned hi_limit, const double2* __restrict__ tab, int j0,
+                                                     float sxn, float sxd, float syn, float syd, int* iu, int* iv)
+{
+#pragma unroll
+    for (int i = 0; i < PXT; i++) {
+        double X, Y, W;
+        double2 o;
+        unsigned qhi;
+        coord_fast(r, tab, j0 + i, X, Y, W, qhi, o.x, o.y);
+        if (!lens_ok(W, qhi, hi_limit)) {
+            ray_cold(r, j0 + i, X, Y, W);
+            o = fisheye_uv32_exact(xf.f[0], xf.f[1], xf.c[0], xf.c[1], lk.k[0], lk.k[1], lk.k[2], lk.k[3], X, Y, W);
+        }
+        float fx = (float)(o.x*(1.0/32)), fy = (float)(o.y*(1.0/32));
+        fx = __fdiv_rn(__fmul_rn(fx, sxn), sxd);
+        fy = __fdiv_rn(__fmul_rn(fy, syn), syd);
+        const int ix = cv_round_f(__fmul_rn(fx, 32.f)), iy = cv_round_f(__fmul_rn(fy, 32.f));
+        iu[i] = (sat_s16(ix >> INTER_BITS) << INTER_BITS) | (ix & 31);
+        iv[i] = (sat_s16(iy >> INTER_BITS) << INTER_BITS) | (iy & 31);
+    }
+}
+
 __device__ __forceinline__ void load_lens_table(const double* __restrict__ g, double2* s_tab)
 {
     const double2* g2 = (const double2*)g;
@@ -847,6 +872,10 @@ struct RemapArgs {
     int tiles_x, tiles_y;
     int cval[3];
     int dst_vec_ok;        // dst base/step/frame stride allow 4-byte (u8) / 8-byte (u16) vector stores
+    // stretched presets (calibrate_video.py:375-380): map coordinates go through float32, are rescaled as numpy does it
+    // (multiply, round, divide, round) and converted like cv::convertMaps.  Only the DIRECT kernel reads these.
+    int stretch_on;
+    float sxn, sxd, syn, syd;
 };
 
 // K1: fused fisheye map + rotation + bilinear remap, batched over frames.
@@ -921,7 +950,8 @@ __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapAr
             const int y = ty*TILE_H + pass*PASS_H + ly;
             if (y >= A.dh) break;
             int iu[PXT], iv[PXT];
-            coord_q5x4(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, iu, iv);
+            if (A.stretch_on) coord_q5x4_stretched(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, A.sxn, A.sxd, A.syn, A.syd, iu, iv);
+            else coord_q5x4(row_consts(xf, y), xf, lk, hi_limit, s_tab, x0, iu, iv);
             int px[PXT][3];
             const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
             uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
@@ -2299,6 +2329,7 @@ RemapArgs make_args(int depth, const void* src, int sw, int sh, size_t sstep, si
     cval_from(bv, depth, A.cval);
     const size_t al = depth == GF_DEPTH_U8 ? 4 : 8;
     A.dst_vec_ok = (((uintptr_t)dst % al) == 0 && (dstep % al) == 0 && (dframe % al) == 0) ? 1 : 0;
+    A.stretch_on = 0; A.sxn = A.sxd = A.syn = A.syd = 1.f;
     return A;
 }
 
@@ -2755,10 +2786,15 @@ struct FusedEnv { int k1_mode; int n_cu; const double* rp_tab; };
 
 static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                         void* dst, int dw, int dh, size_t dstep, size_t dframe, const double* lens, LensK lk,
-                        const gf_frame_xform* xf_dev, int n_frames, int border, const double* bv, hipStream_t stream)
+                        const gf_frame_xform* xf_dev, int n_frames, int border, const double* bv, hipStream_t stream,
+                        const float* stretch = nullptr)
 {
     RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
-    if (c->k1_mode != GF_KERNEL_DIRECT) {
+    if (stretch && !(stretch[0] == 1.f && stretch[1] == 1.f && stretch[2] == 1.f && stretch[3] == 1.f)) {
+        A.stretch_on = 1; A.sxn = stretch[0]; A.sxd = stretch[1]; A.syn = stretch[2]; A.syd = stretch[3];
+    }
+    // stretched presets take their coordinates through float32 maps, which get_maps builds from the per-pixel (DIRECT) path
+    if (c->k1_mode != GF_KERNEL_DIRECT && !stretch) {
         // RP coordinates on 64 x 64 tiles (mode RP, the default); in mode RL u8 frames with 16-byte aligned base, row pitch and
         // frame stride also stage their source taps through LDS
         A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
@@ -2820,6 +2856,27 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
     return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
                         border, bv, (hipStream_t)stream);
+}
+
+GF_API int gf_undistort_rotate_stretched_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                                     void* dst, int dw, int dh, size_t dstep, size_t dframe,
+                                     const double D[4], const gf_frame_xform* xf_dev, int n_frames,
+                                     float sx_num, float sx_den, float sy_num, float sy_den,
+                                     int border, const double bv[4], gf_stream_t stream)
+{
+    int rc = fused_checks("gf_undistort_rotate_stretched_c3", ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_frames, n_frames, border);
+    if (rc) return rc;
+    if (sx_den == 0.f || sy_den == 0.f) return fail(GF_ERR_INVALID_ARG, "%s: zero scale denominator", "gf_undistort_rotate_stretched_c3");
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", "gf_undistort_rotate_stretched_c3");
+    const double* lens; LensK lk;
+    LensLease lease(c, (hipStream_t)stream);
+    rc = lease.acquire(D, &lens, &lk); if (rc) return rc;
+    const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
+    const float sc[4] = {sx_num, sx_den, sy_num, sy_den};
+    return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
+                        border, bv, (hipStream_t)stream, sc);
 }
 
 GF_API int gf_undistort_rotate_superview_u8c3(void* ctx, const uint8_t* src, int sw, int sh, size_t sstep, size_t sframe,

@@ -196,11 +196,13 @@ def _frames4(t, what):
     return t
 
 
-def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0):
+def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0, map_scale=None):
     """Fused get_maps + remap(INTER_LINEAR) for a batch of frames (stabilizer.py:1423-1443 per frame).
 
     src: CUDA uint8/uint16 [N,H,W,3] (or [H,W,3]; a stride-0 expand() over N reuses one input frame).
-    D: the lens's distortion coefficients k1..k4 (host).  xforms_dev: CUDA float64 [N,13] from xforms_to_device().  Returns dst [N,out_h,out_w,3]."""
+    D: the lens's distortion coefficients k1..k4 (host).  xforms_dev: CUDA float64 [N,13] from xforms_to_device().
+    map_scale = (sx_num, sx_den, sy_num, sy_den): the float32 map rescale of a stretched preset (calibrate_video.py:375-380;
+    FisheyeCalibrator.map_scale()), None for ordinary presets.  Returns dst [N,out_h,out_w,3]."""
     if not (isinstance(src, torch.Tensor) and src.is_cuda):
         raise TypeError("undistort_rotate works on CUDA tensors")
     dev = src.device
@@ -219,9 +221,15 @@ def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_C
     esz = s.element_size()
     lib, ctx = _lib.load(), _lib.ctx(dev.index)
     with torch.cuda.device(dev):
-        _lib.check(lib.gf_undistort_rotate_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
-                                              _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _lib.distortion(D),
-                                              _ptr(xforms_dev), n, int(borderMode), _lib.border_value(borderValue), _stream(dev)))
+        if map_scale is None:
+            _lib.check(lib.gf_undistort_rotate_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
+                                                  _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _lib.distortion(D),
+                                                  _ptr(xforms_dev), n, int(borderMode), _lib.border_value(borderValue), _stream(dev)))
+        else:
+            _lib.check(lib.gf_undistort_rotate_stretched_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
+                                                            _ptr(d), dw, dh, d.stride(1) * esz, d.stride(0) * esz, _lib.distortion(D),
+                                                            _ptr(xforms_dev), n, float(map_scale[0]), float(map_scale[1]), float(map_scale[2]),
+                                                            float(map_scale[3]), int(borderMode), _lib.border_value(borderValue), _stream(dev)))
     return d if (dst is None or dst.dim() == 4) else d[0]
 
 

@@ -352,7 +352,7 @@ class Stabilizer:
         if borderMode == cv.BORDER_TRANSPARENT:
             sequential = True
         lo, hi = frame_shard(max(num_frames - 1, 0), rank, world, mult)     # the loop runs i = 1 .. num_frames-1
-        stretched = self.undistort.image_is_stretched()
+        stretched = self.undistort.image_is_stretched() and nblend > 1      # the fused blend kernel has no stretched-preset form
 
         old_map_enable_setting = False
         if viewer_thread is not None and display_preview:
@@ -441,7 +441,8 @@ class Stabilizer:
 
             def launch(din, dout, dxf):
                 if nblend == 1:
-                    cv.undistort_rotate(din, self.undistort.D, dxf, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue)
+                    cv.undistort_rotate(din, self.undistort.D, dxf, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue,
+                                        map_scale=self.undistort.map_scale())
                 else:
                     cv.undistort_rotate_blend(din, self.undistort.D, dxf, out_size, nblend, nblend, dst=dout[:n_groups],
                                               borderMode=borderMode, borderValue=borderValue)
@@ -577,7 +578,7 @@ class OnlyUndistort:
                 return
             n = len(pend)
             pipe.submit(pend, lambda din, dout, dxf: (cv.undistort_rotate(din, self.undistort.D, dxf, (map_w, map_h), dst=dout[:n],
-                                                                          borderMode=cv.BORDER_CONSTANT), n)[1],
+                                                                          borderMode=cv.BORDER_CONSTANT, map_scale=self.undistort.map_scale()), n)[1],
                         xf=np.tile(xf1, (n, 1)))
             pend = []
 

@@ -152,6 +152,18 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
                            const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
                            int border, const double border_value_host[4], gf_stream_t stream);
 
+/* The fused hot path for STRETCHED presets (input_horizontal_stretch != 1): get_maps' other branch,
+ *   replaces calibrate_video.py:376-380 (CV_32FC1 maps, `map1 * orig_w / calib_w`, `map2 * orig_h / calib_h` in float32,
+ *   cv2.convertMaps) + stabilizer.py:1442-1443, for a batch of frames.
+ * Per pixel the coordinate goes through float32, is multiplied by s*_num and divided by s*_den in float32 (two roundings
+ * each, as numpy evaluates it) and rounded to Q5 like cv::convertMaps.  Output is bit-identical to gf_fisheye_maps_32f +
+ * gf_convert_maps_32f_16sc2 + gf_remap_linear_c3.  Other arguments as gf_undistort_rotate_c3. */
+GF_API int gf_undistort_rotate_stretched_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                                     void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                                     const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
+                                     float sx_num, float sx_den, float sy_num, float sy_den,
+                                     int border, const double border_value_host[4], gf_stream_t stream);
+
 /* BASELINE config C4 in one launch: gf_undistort_rotate_c3 (u8) into an intermediate image of mid_w x mid_h, then
  * gf_superview_cubic_u8c3 (BORDER_CONSTANT 0, as NonlinearStretch.apply_stretch calls cv2.remap) to dst -- with the
  * intermediate image living tile by tile in LDS instead of HBM

@@ -69,3 +69,30 @@ def test_fused_blend_equals_separate_passes_c5(gpu):
     for b in range(4):
         t += (1 / 4) * remapped[b].to(torch.float64)
     assert torch.equal(want.to(torch.int32), t.to(torch.int32))
+
+
+@pytest.mark.parametrize("border", [0, 1])
+def test_stretched_preset_fused_equals_get_maps_plus_remap(gpu, border):
+    """Stretched presets (calibrate_video.py:375-380) on the batched fused path: runcam5_stretched, 3840x2160 video ->
+    1920x1080, per-frame rotations: gf_undistort_rotate_stretched_c3 == get_maps (float32 maps, numpy-style float32 rescale,
+    convertMaps) + remap, bit for bit."""
+    from gyroflow_amd import FisheyeCalibrator, synthetic_frames, cv
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("runcam5_stretched"))
+    assert cal.image_is_stretched() and cal.map_scale() is not None
+    w, h = (int(v) for v in cal.orig_dimension)
+    ow, oh = 1920, 1080
+    n = 3
+    q = np.load(os.path.join(GOLDEN, "quats_gyroflow_sample.npz"))["stab_transform"][100:100 + 50 * n:50, 3:7]
+    frames = torch.from_numpy(np.stack(synthetic_frames(w, h, n=n, seed=19))).to(gpu)
+    fov = np.array([1.0, 1.3, 0.8])
+    fc = np.array([[cal.calib_dimension[0] / 2 + 11 * i, cal.calib_dimension[1] / 2 - 7 * i] for i in range(n)], np.float64)
+    xf = cal.frame_xforms(fov, q, output_dim=(ow, oh), new_img_dim=(w, h), focalCenters=fc)
+    for i in range(n):
+        np.testing.assert_array_equal(xf[i], cal.frame_xform(float(fov[i]), (ow, oh), (w, h), q[i], fc[i]))
+    fused = cv.undistort_rotate(frames, cal.D, cv.xforms_to_device(xf, gpu), (ow, oh), borderMode=border, borderValue=(4, 5, 6),
+                                map_scale=cal.map_scale())
+    for i in range(n):
+        m1, m2 = cal.get_maps(float(fov[i]), new_img_dim=(w, h), output_dim=(ow, oh), update_new_K=False, quat=q[i], focalCenter=fc[i], device=gpu)
+        two = cv.remap(frames[i], m1, m2, cv.INTER_LINEAR, borderMode=border, borderValue=(4, 5, 6))
+        assert torch.equal(fused[i], two), "frame %d" % i

@@ -309,3 +309,22 @@ def test_two_rank_render_equals_single_rank(gpu, mult, nblend):
     assert len(r0) > 0 and len(r1) > 0 and len(r0) + len(r1) == len(single)
     for a, b in zip(r0 + r1, single):
         np.testing.assert_array_equal(a, b)
+
+
+def test_renderfile_stretched_preset_batched_equals_sequential(gpu):
+    """A stretched preset renders through the batched fused path; the frames equal the per-frame sequence get_maps ->
+    convertMaps -> remap (sequential=True)."""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, synthetic_frames
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("runcam5_stretched"))
+    w, h, n = 480, 270, 14                      # the 3840x2160 video of the preset, divided by 8
+    frames = synthetic_frames(w, h, n=n, seed=13)
+    stab = _quats(n + 2, seed=8)
+    outs = []
+    for seq in (False, True):
+        st = Stabilizer(ArraySource(frames), cal, stab, 10.0, w, h, device=gpu)
+        sink = ListSink()
+        assert st.renderfile(0.0, 1.35, sink, out_size=(320, 180), smoothingFocus=-2, fov_scale=1.1, bg_color="REPLICATE", batch=5, sequential=seq) == 12
+        outs.append(sink.frames)
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a, b)
