@@ -24,6 +24,7 @@
 //    polynomials (64 x 64 tiles) instead of the per-pixel table lookup described above (DIRECT); RL additionally stages the
 //    source box of a tile in LDS by LDS-DMA.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <string.h>
 #include <limits.h>
@@ -1840,6 +1841,8 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
     cpat.a = cpix | (cpix << 24); cpat.b = (cpix >> 8) | (cpix << 16); cpat.c = (cpix >> 16) | (cpix << 8);
 #pragma unroll 1
     for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+        // Plain row-major strip order.  Measured (C4, 128 frames): the XCD-banded order of the fused kernels' tiles is 9 % slower
+        // here (3.33 vs 3.06 ms) -- this kernel is bound by VALU issue, not by what its strips share in L2.
         const unsigned frame = v / per_frame, t = v - frame*per_frame;
         const unsigned syi = t / strips_x, sxi = t - syi*strips_x;
         const uint8_t* S = src + (size_t)frame*sframe;
@@ -1929,6 +1932,11 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
             // lanes 0..2 of a quad write dword qj of its 12 bytes; lane 3 repeats lane 2's store (same address, same value)
             uint8_t* const Dlane = Dst + (size_t)x*3 + (qj < 3 ? qj : -1);
             const unsigned st_sh = qj < 3 ? 8u + 8u*(unsigned)qj : 24u;
+            // one vertical fraction for the whole strip (what a unit vertical scale gives): the 16 weights of a lane are then
+            // the same for every row and are read from the table once, not per pixel
+            const int fy0 = __builtin_amdgcn_readlane(isy_lane, 0) & 31;
+            const bool fy_const = __all(lane >= nrows || (isy_lane & 31) == fy0);
+            const uint4 cw0 = s_tab[(fy0*32 + fx)*2], cw1 = s_tab[(fy0*32 + fx)*2 + 1];
             auto rows_ok = [&](int sy) { return border1 != GF_BORDER_CONSTANT || (sy >= 0 && sy + SV_G + 2 <= sh - 1); };
             auto loadw = [&](int sy) { return *(const uint32_t*)(S + (size_t)max(border_interp(sy, sh, border1), 0)*sstep + ld_off); };
             auto gather = [&](uint32_t w) {
@@ -1940,6 +1948,7 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
                 r.a = __builtin_amdgcn_alignbit(w1, w0, coop_sh); r.b = __builtin_amdgcn_alignbit(w2, w1, coop_sh); r.c = __builtin_amdgcn_alignbit(w3, w2, coop_sh);
                 return sv_unpack(r);
             };
+            auto fast_rows = [&](auto one_fy) {                           // one_fy: std::true_type when fy_const
 #pragma unroll 1
             while (i + SV_G <= nrows) {
                 int sy0 = row_of(i);
@@ -1962,8 +1971,12 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
                     for (int k = 0; k < SV_G; k++) nw[k] = loadw(sy0 + SV_G + 3 + k);      // used only when `more`
 #pragma unroll
                     for (int k = 0; k < SV_G; k++) {
-                        const int e = ((__builtin_amdgcn_readlane(isy_lane, i + k) & 31)*32 + fx)*2;
-                        const uint32_t px = sv_pixel(R[k], R[k + 1], R[k + 2], R[k + 3], s_tab[e], s_tab[e + 1]);
+                        uint4 wa = cw0, wb = cw1;
+                        if constexpr (!decltype(one_fy)::value) {
+                            const int e = ((__builtin_amdgcn_readlane(isy_lane, i + k) & 31)*32 + fx)*2;
+                            wa = s_tab[e]; wb = s_tab[e + 1];
+                        }
+                        const uint32_t px = sv_pixel(R[k], R[k + 1], R[k + 2], R[k + 3], wa, wb);
                         const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
                         const uint32_t lf = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0x90, 0xF, 0xF, true);      // quad_perm [0,0,1,2]: left neighbour
                         *(uint32_t*)(Dlane + (size_t)(y0 + i + k)*dstep) = __builtin_amdgcn_alignbit(qj < 3 ? nb : px, (qj < 3 ? px : lf) << 8, st_sh);
@@ -1974,6 +1987,8 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
                     if (!more) break;
                 }
             }
+            };
+            if (fy_const) fast_rows(std::true_type{}); else fast_rows(std::false_type{});
         }
 
         // Generic rows: edge waves, the transparent border, vertical steps other than 1, and what the fast loop left.
