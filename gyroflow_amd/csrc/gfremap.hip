@@ -1805,6 +1805,15 @@ __device__ __forceinline__ int sv_dot(uint32_t a, uint32_t w, int acc)
 
 // One pixel from the window rows U0..U3 (source rows sy..sy+3) and the table entry's 16 halfwords (w0, w1):
 // returns B | G << 8 | R << 16.
+// Buffer addressing for the superview fast loop: the frame is one buffer resource (scalar), a row is the scalar offset
+// row * step and the lane supplies a 32-bit byte offset, so a load or store needs no per-lane 64-bit address arithmetic (with
+// plain pointers the compiler folds the lane offset into a per-lane 64-bit base and pays a v_mad_u64_u32 or v_lshl_add_u64 per
+// access).  Reads past the resource's size return 0 and such writes are dropped, but nothing here relies on that.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t frame_rsrc(const void* base, unsigned bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
 __device__ __forceinline__ uint32_t sv_pixel(const SvRow& U0, const SvRow& U1, const SvRow& U2, const SvRow& U3, const uint4 w0, const uint4 w1)
 {
     int sb = 1 << 14, sg = 1 << 14, sr = 1 << 14;
@@ -1834,6 +1843,7 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
     __syncthreads();
     const unsigned per_frame = strips_x*strips_y;
     const int lane = threadIdx.x & 63;
+    const bool small_frames = (uint64_t)sstep*(unsigned)sh < (1ull << 31) && (uint64_t)dstep*(unsigned)dh < (1ull << 31);      // 32-bit buffer offsets
     const bool transparent = border == GF_BORDER_TRANSPARENT;
     const int border1 = transparent ? 4 : border;                      // taps of a written pixel reflect (as cubic_px)
     const uint32_t cpix = (uint32_t)(c0 & 255) | ((uint32_t)(c1 & 255) << 8) | ((uint32_t)(c2 & 255) << 16);
@@ -1914,7 +1924,8 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
         for (int k = 0; k < SV_G + 3; k++)
 #pragma unroll
             for (int j = 0; j < 6; j++) R[k].p[j] = 0;
-        auto row_of = [&](int r) { return sat_s16(__builtin_amdgcn_readlane(isy_lane, r) >> INTER_BITS) - 1; };      // r < 64, uniform
+        // r < 64; uniform, and said so: everything derived from it (row addresses) then stays in scalar registers
+        auto row_of = [&](int r) { return __builtin_amdgcn_readfirstlane(sat_s16(__builtin_amdgcn_readlane(isy_lane, r) >> INTER_BITS) - 1); };
         auto group_runs = [&](int r, int sy) {                          // output rows r .. r + SV_G - 1 read source rows sy, sy + 1, ...
             bool ok = true;
 #pragma unroll
@@ -1926,11 +1937,12 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
         // Fast loop: a wave whose lanes all fetch cooperatively and all write.  Straight-line code, no branch around a
         // memory instruction, so that the rows the next group adds are requested *before* this group's stores are queued
         // and waiting for them does not wait for the stores (vector loads and stores complete in issue order).
-        if (coop && !transparent && dst_vec_ok && wr_mask == ~0ull) {
+        if (coop && !transparent && dst_vec_ok && wr_mask == ~0ull && small_frames) {
             const unsigned ld_off = min(coop_ld, (coop_end - 1u) & ~3u);            // lanes past the span re-read its last dword
             const int qj = lane & 3;
             // lanes 0..2 of a quad write dword qj of its 12 bytes; lane 3 repeats lane 2's store (same address, same value)
-            uint8_t* const Dlane = Dst + (size_t)x*3 + (qj < 3 ? qj : -1);
+            const unsigned dl_off = (unsigned)x*3u + (qj < 3 ? (unsigned)qj : ~0u);      // x >= 3 for a quad's lane 3
+            const __amdgpu_buffer_rsrc_t srs = frame_rsrc(S, sstep*(unsigned)sh), drs = frame_rsrc(Dst, (unsigned)dstep*(unsigned)dh);
             const unsigned st_sh = qj < 3 ? 8u + 8u*(unsigned)qj : 24u;
             // one vertical fraction for the whole strip (what a unit vertical scale gives): the 16 weights of a lane are then
             // the same for every row and are read from the table once, not per pixel
@@ -1938,7 +1950,11 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
             const bool fy_const = __all(lane >= nrows || (isy_lane & 31) == fy0);
             const uint4 cw0 = s_tab[(fy0*32 + fx)*2], cw1 = s_tab[(fy0*32 + fx)*2 + 1];
             auto rows_ok = [&](int sy) { return border1 != GF_BORDER_CONSTANT || (sy >= 0 && sy + SV_G + 2 <= sh - 1); };
-            auto loadw = [&](int sy) { return *(const uint32_t*)(S + (size_t)max(border_interp(sy, sh, border1), 0)*sstep + ld_off); };
+            // scalar row base + 32-bit lane offset: no per-lane 64-bit address arithmetic
+            auto loadw = [&](int sy) {
+                const unsigned ry = (unsigned)__builtin_amdgcn_readfirstlane(max(border_interp(sy, sh, border1), 0));
+                return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(srs, (int)ld_off, (int)(ry*sstep), 0);
+            };
             auto gather = [&](uint32_t w) {
                 const uint32_t w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(coop_sel, (int)w);
                 const uint32_t w1 = (uint32_t)__builtin_amdgcn_ds_bpermute(coop_sel + 4, (int)w);
@@ -1979,7 +1995,8 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
                         const uint32_t px = sv_pixel(R[k], R[k + 1], R[k + 2], R[k + 3], wa, wb);
                         const uint32_t nb = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0xF9, 0xF, 0xF, true);      // quad_perm [1,2,3,3]: right neighbour
                         const uint32_t lf = (uint32_t)__builtin_amdgcn_mov_dpp((int)px, 0x90, 0xF, 0xF, true);      // quad_perm [0,0,1,2]: left neighbour
-                        *(uint32_t*)(Dlane + (size_t)(y0 + i + k)*dstep) = __builtin_amdgcn_alignbit(qj < 3 ? nb : px, (qj < 3 ? px : lf) << 8, st_sh);
+                        __builtin_amdgcn_raw_buffer_store_b32((int)__builtin_amdgcn_alignbit(qj < 3 ? nb : px, (qj < 3 ? px : lf) << 8, st_sh), drs, (int)dl_off,
+                                                              (int)((unsigned)__builtin_amdgcn_readfirstlane(y0 + i + k)*(unsigned)dstep), 0);
                     }
 #pragma unroll
                     for (int k = 0; k < 3; k++) R[k] = R[SV_G + k];
