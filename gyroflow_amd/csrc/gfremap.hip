@@ -1851,6 +1851,14 @@ __global__ void __launch_bounds__(BLOCK) k_superview_cubic(const uint8_t* __rest
     cpat.a = cpix | (cpix << 24); cpat.b = (cpix >> 8) | (cpix << 16); cpat.c = (cpix >> 16) | (cpix << 8);
 #pragma unroll 1
     for (unsigned v = blockIdx.x; v < n_work; v += gridDim.x) {
+#ifdef GF_SV_STRIP_SYNC
+        // Measurement switch, off: a barrier per strip keeps the four waves on the same strip (no data is exchanged: this is about
+        // time).  Their row windows share 128-byte lines, and without it the waves drift apart by whole strips over the persistent
+        // loop, so the shared lines have left L1 and L2 when the sibling wave asks: L2 misses to memory 38.2 M -> 26.6 M per 128
+        // C4 frames with the barrier (2.05x -> 1.42x the source bytes) -- but 2.75 -> 2.86 ms, because the kernel is bound by VALU
+        // issue and the waves now wait for each other.  Speed was chosen.
+        __builtin_amdgcn_s_barrier();
+#endif
         // Plain row-major strip order.  Measured (C4, 128 frames): the XCD-banded order of the fused kernels' tiles is 9 % slower
         // here (3.33 vs 3.06 ms) -- this kernel is bound by VALU issue, not by what its strips share in L2.
         const unsigned frame = v / per_frame, t = v - frame*per_frame;
