@@ -202,3 +202,32 @@ def test_fused_superview_random_case(gpu, seed):
     # the border mode is the remap step's (stabilizer.py:1442); the stretch step keeps the reference's default, constant 0
     # (nonlinear_stretch.py:130) -- in the one-launch form too
     assert torch.equal(one, two), "case %d: %dx%d -> %dx%d -> %dx%d" % (seed, sw, sh, mw, mh, ow, oh)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fused_stretched_random_case(gpu, orc, seed):
+    """gf_undistort_rotate_stretched_c3 == float32 maps, numpy's float32 rescale, convertMaps, remap (calibrate_video.py:375-380
+    followed by stabilizer.py:1442) on the GPU bit for bit, and the rescale + convertMaps step against the oracle."""
+    from gyroflow_amd import cv, _lib
+    c = _case(200 + seed)
+    rng, sw, sh, dw, dh, n, dtype, border = c["rng"], c["sw"], c["sh"], c["dw"], c["dh"], c["n"], c["dtype"], c["border"]
+    scale = (float(rng.integers(100, 4000)), float(rng.integers(100, 4000)), float(rng.integers(100, 3000)), float(rng.integers(100, 3000)))
+    frames = np.stack([_img(rng, sh, sw, dtype) for _ in range(n)])
+    prev = np.stack([_img(rng, dh, dw, dtype) for _ in range(n)])
+    xf = cv.xforms_to_device(np.stack([_lib.xform_to_array(_lib.make_frame_xform(c["K"], R, c["P"])) for R in c["Rs"]]), gpu)
+    bv = (5, 90, 250)
+    got = cv.undistort_rotate(torch.from_numpy(frames).to(gpu), c["D"], xf, (dw, dh), dst=torch.from_numpy(prev.copy()).to(gpu),
+                              borderMode=border, borderValue=bv, map_scale=scale).cpu().numpy()
+    for i in range(n):
+        f1, f2 = cv.fisheye_initUndistortRectifyMap(c["K"], c["D"], c["Rs"][i], c["P"], (dw, dh), cv.CV_32FC1, device=gpu)
+        g1, g2 = cv.convertMaps(f1, f2, cv.CV_16SC2, scale_x=scale[:2], scale_y=scale[2:])
+        want = cv.remap(torch.from_numpy(frames[i]).to(gpu), g1, g2, cv.INTER_LINEAR, dst=torch.from_numpy(prev[i].copy()).to(gpu),
+                        borderMode=border, borderValue=bv).cpu().numpy()
+        np.testing.assert_array_equal(got[i], want, err_msg="frame %d of case %d" % (i, seed))
+        # the reference's own arithmetic: float32 numpy multiply, then divide (two roundings each), then convertMaps
+        n1 = f1.cpu().numpy() * np.float32(scale[0]) / np.float32(scale[1])
+        n2 = f2.cpu().numpy() * np.float32(scale[2]) / np.float32(scale[3])
+        assert n1.dtype == np.float32
+        o1, o2 = orc.convert_maps(n1, n2)
+        np.testing.assert_array_equal(g1.cpu().numpy(), o1)
+        np.testing.assert_array_equal(g2.cpu().numpy(), o2)
