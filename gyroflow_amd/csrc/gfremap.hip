@@ -1308,7 +1308,9 @@ __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(Rema
                 }
             }
         }
+#ifndef GF_ABL_NOBARRIER     /* tools/ ablation builds only (racy coefficient buffers, wrong pixels): the per-item barrier costs 2.8 % */
         lds_barrier();
+#endif
     }
 #ifdef GF_TRACE_WG
     if (threadIdx.x == 0 && blockIdx.x < 8192) g_wg_trace[blockIdx.x][1] = wall_clock64();
