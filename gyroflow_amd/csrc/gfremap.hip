@@ -2845,7 +2845,9 @@ static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, i
         if (n_work >= (1ull << 31)) return fail(GF_ERR_UNSUPPORTED, "%s: too many tiles in one call (%lld)", "gf_undistort_rotate_c3", (long long)n_work);
         const bool ldsbox = c->k1_mode == GF_KERNEL_RL && depth == GF_DEPTH_U8 && ((uintptr_t)src & 15) == 0 && (sstep & 15) == 0 && (sframe & 15) == 0 &&
                             (size_t)(sh - 1)*sstep + (size_t)sw*3 >= 32;
-        const unsigned wg_rp = WG_PER_CU_RP ? WG_PER_CU_RP : (n_work >= (unsigned long long)c->n_cu*32u*24u ? 32u : 16u);
+        // 32 workgroups per CU once each still gets >= 7 work items, else 16 (tools/wg_sweep.sh, C3: 64 frames 20.3 -> 19.7 us/frame,
+        // 32 frames 21.3 -> 21.0, 16 frames 22.6 with 16 against 23.3 with 32; 40..64 per CU change nothing)
+        const unsigned wg_rp = WG_PER_CU_RP ? WG_PER_CU_RP : (n_work >= (unsigned long long)c->n_cu*32u*7u ? 32u : 16u);
         unsigned blocks = (unsigned)c->n_cu*(ldsbox ? WG_PER_CU_RL : wg_rp) & ~(unsigned)(NXCD - 1);
         if (blocks == 0) blocks = NXCD;
         if (blocks > n_work) blocks = (unsigned)n_work;
