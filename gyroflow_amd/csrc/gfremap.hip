@@ -54,7 +54,7 @@ constexpr int TPR = TILE_W/PXT;               // threads per tile row
 constexpr int PASS_H = BLOCK/TPR;             // rows per pass
 static_assert(TILE_W % PXT == 0 && BLOCK % TPR == 0 && TILE_H % PASS_H == 0 && (TPR & (TPR - 1)) == 0, "tile shape");
 constexpr int NXCD = 8;
-const unsigned WG_PER_CU = getenv("GF_WG_PER_CU") ? (unsigned)atoi(getenv("GF_WG_PER_CU")) : 24u;  // persistent fused kernel: workgroups per CU (5 are resident; the surplus evens out the tail, measured +4 %)
+const unsigned WG_PER_CU = getenv("GF_WG_PER_CU") ? (unsigned)atoi(getenv("GF_WG_PER_CU")) : 24u;  // persistent fused kernel: workgroups per CU (4 are resident; the surplus evens out the tail, measured +4 %)
 
 // lens table: q = 1 + t in [1, 2^LENS_OCT), 2^LENS_SUB_BITS pieces per octave; per piece the centre q_mid and the
 // LENS_DEG+1 coefficients of a polynomial in (q - q_mid): 8 doubles = 64 bytes
@@ -901,7 +901,8 @@ __device__ __forceinline__ bool tile_of_padded_id(unsigned w, int tiles_x, int t
 #define GF_K1_PIPELINE 0
 #endif
 #ifndef GF_K1_WAVES
-#define GF_K1_WAVES 5
+#define GF_K1_WAVES 4       /* 121 VGPRs; at 5 (96 VGPRs) the kernel spills 21 registers since it also carries the stretched-preset
+                               rescale, and runs at half the speed (43.9 vs 21.5 us per C3 frame, tools/direct_ab.sh) */
 #endif
 template <int DEPTH, int BORDER>
 __global__ void __launch_bounds__(BLOCK, GF_K1_WAVES) k_undistort_rotate(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
