@@ -437,3 +437,20 @@ def test_library_has_no_forbidden_instruction():
         dis = subprocess.check_output([objdump, "-d", os.path.join(d, cos[0])]).decode()
     assert "v_dot4_u32_u8" in dis            # the disassembly is the device code of the fused kernel
     assert "v_ashr_pk_u8_i32" not in dis
+
+
+def test_threaded_staging_copy_equals_plain_copy():
+    """pipeline._host_copy (the decoder-output -> pinned-slot copy, row bands on a thread pool) for frames above and below its
+    size threshold, both depths, a source with padded rows and a row count that does not divide by the thread count."""
+    from gyroflow_amd import pipeline
+    rng = np.random.default_rng(3)
+    for shape, dt in (((1081, 1920, 3), np.uint8), ((37, 53, 3), np.uint8), ((1500, 1000, 3), np.uint16)):
+        src = rng.integers(0, np.iinfo(dt).max, shape).astype(dt)
+        dst = np.zeros(shape, dt)
+        pipeline._host_copy(dst, src)
+        np.testing.assert_array_equal(dst, src)
+        padded = np.zeros((shape[0], shape[1] + 7, 3), dt)
+        padded[:, :shape[1]] = src
+        dst[...] = 0
+        pipeline._host_copy(dst, padded[:, :shape[1]])
+        np.testing.assert_array_equal(dst, src)
