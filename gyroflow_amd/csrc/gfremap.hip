@@ -1572,8 +1572,12 @@ __global__ void __launch_bounds__(BLOCK) k_remap_linear(RemapArgs A, const uint8
 // separate passes bit for bit in the RP / RL modes too): one 64 x 64 tile of one output frame per workgroup.  The
 // coefficients of all n_blend <= RB (4 or RB_MAX) input frames are prepared first (four frames at a time, one wave per frame), then
 // the pixels are produced row pass by row pass with the blend loop innermost, as in k_undistort_rotate_blend.
+// POW2: n_blend is a power of two.  Then 1/n_blend, every product (1/n_blend) * pixel and every partial sum of the reference's
+// float64 accumulation (frame_temp += (1/N) * frame.astype(float64)) are exact, so the truncated result is (sum of the pixels)
+// >> log2(n_blend), and the sum is kept as an integer: 12 additions per input frame and pass instead of 12 conversions, 12
+// float64 multiplies and 12 float64 additions.  Other n_blend keep the float64 arithmetic in the reference's order.
 constexpr int RB_MAX = 8;
-template <int DEPTH, int BORDER, int RB>
+template <int DEPTH, int BORDER, int RB, bool POW2>
 __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
                                                                       const double* __restrict__ rp_tab, int frames_per_group, int n_blend)
 {
@@ -1583,12 +1587,14 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A
     __shared__ double C2[BLOCK/64][RP_N][RP_N];
     __shared__ double C[RB][RT][RP_N];
     __shared__ int okf[RB];
+    __shared__ RpFrameC FC[RB];                  // the frames' constants, once per workgroup instead of once per pass and frame
     load_lens_table(lens, s_tab);
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     rp_load_consts(rp_tab, K, tid, BLOCK);
     int tx, ty;
     tile_of_block(blockIdx.x, A.tiles_x, A.tiles_y, tx, ty);
     const int g = blockIdx.y;
+    if (tid < n_blend) FC[tid] = rp_frame_consts(xfs[g*frames_per_group + tid]);
     const double offx = rp_node_off(rp_tab, lane & 7), offy = rp_node_off(rp_tab, lane >> 3);
     __syncthreads();
 #pragma unroll 1
@@ -1606,32 +1612,40 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A
 #pragma unroll
     for (int e = 0; e < PXT; e++) z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);
     const double wgt = 1.0/(double)n_blend;       // Python: 1/(self.hyperlapse_num_blended_frames)
+    const int shift = 31 - __builtin_clz((unsigned)n_blend);      // log2(n_blend) when POW2
+    typedef typename std::conditional<POW2, unsigned, double>::type AccT;
 #pragma unroll 1
     for (int pass = 0; pass < RT_NPASS; pass++) {
         const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
         if (y >= A.dh) break;
-        double acc[PXT][3];
+        AccT acc[PXT][3];
 #pragma unroll
-        for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0.0;
+        for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0;
 #pragma unroll 1
         for (int b = 0; b < n_blend; b++) {
             const int frame = g*frames_per_group + b;
             const Xf& xf = xfs[frame];
             const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
             int iu[PXT], iv[PXT], o[PXT][3];
-            if (okf[b]) rp_coords(rp_row_consts(rp_frame_consts(xf), y), C[b][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
+            if (okf[b]) rp_coords(rp_row_consts(FC[b], y), C[b][rr], z, x0, ROUND_MAGIC, ROUND_MAGIC, iu, iv);
             else coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
             remap4<DEPTH, BORDER>(s, iu, iv, A.cval, o);
 #pragma unroll
             for (int i = 0; i < PXT; i++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[i][c]));
+                for (int c = 0; c < 3; c++) {
+                    if constexpr (POW2) acc[i][c] += (unsigned)o[i][c];
+                    else                acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[i][c]));
+                }
         }
         int px[PXT][3];
 #pragma unroll
         for (int i = 0; i < PXT; i++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) px[i][c] = (int)acc[i][c];      // astype(uint): truncation
+            for (int c = 0; c < 3; c++) {
+                if constexpr (POW2) px[i][c] = (int)(acc[i][c] >> shift);
+                else                px[i][c] = (int)acc[i][c];          // astype(uint): truncation
+            }
         uint8_t* drow = A.dst + (size_t)g*A.dframe + (size_t)y*A.dstep;
         store_px<DEPTH>(drow, x0, A.dw, px, 0u, A.dst_vec_ok);
     }
@@ -3080,11 +3094,14 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
     if (c->k1_mode != GF_KERNEL_DIRECT && n_blend <= RB_MAX) {      // RP coordinates, as the fused kernel of this mode
         A.tiles_x = (dw + RT - 1)/RT; A.tiles_y = (dh + RT - 1)/RT;
         dim3 grid(A.tiles_x*A.tiles_y, n_out);
-#define LAUNCH_BRP(DEPTH_, BORDER_) do { if (n_blend <= 4) hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_, 4>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend); \
-                                          else hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_, RB_MAX>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend); } while (0)
+#define LAUNCH_BRP2(DEPTH_, BORDER_, RB_, P2_) hipLaunchKernelGGL((k_undistort_rotate_blend_rp<DEPTH_, BORDER_, RB_, P2_>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, frames_per_group, n_blend)
+#define LAUNCH_BRP(DEPTH_, BORDER_) do { const bool p2 = (n_blend & (n_blend - 1)) == 0; \
+                                          if (n_blend <= 4) { if (p2) LAUNCH_BRP2(DEPTH_, BORDER_, 4, true); else LAUNCH_BRP2(DEPTH_, BORDER_, 4, false); } \
+                                          else              { if (p2) LAUNCH_BRP2(DEPTH_, BORDER_, RB_MAX, true); else LAUNCH_BRP2(DEPTH_, BORDER_, RB_MAX, false); } } while (0)
         if (depth == GF_DEPTH_U8) { if (border == GF_BORDER_CONSTANT) LAUNCH_BRP(GF_DEPTH_U8, GF_BORDER_CONSTANT); else LAUNCH_BRP(GF_DEPTH_U8, GF_BORDER_REPLICATE); }
         else                      { if (border == GF_BORDER_CONSTANT) LAUNCH_BRP(GF_DEPTH_U16, GF_BORDER_CONSTANT); else LAUNCH_BRP(GF_DEPTH_U16, GF_BORDER_REPLICATE); }
 #undef LAUNCH_BRP
+#undef LAUNCH_BRP2
         HIP_TRY(hipGetLastError());
         return GF_OK;
     }
