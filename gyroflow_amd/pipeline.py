@@ -89,6 +89,30 @@ class BatchPipeline:
             s["hout_np"] = s["hout"].numpy()
             s["hxf_np"] = s["hxf"].numpy()
         self.k = 0
+        self._trace = None
+
+    # ---- optional timeline of the three streams (tools/render_bench.py --overlap): HIP events around every batch's upload,
+    # kernel and download; off by default (timing events cost a little on every record)
+    def enable_trace(self):
+        with torch.cuda.device(self.dev):
+            self._trace = dict(base=torch.cuda.Event(enable_timing=True), rows=[])
+            self._trace["base"].record(torch.cuda.current_stream(self.dev))
+
+    def _tev(self, stream):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(stream)
+        return ev
+
+    def trace_table(self):
+        """After flush(): one row per batch, times in ms since enable_trace(): h2d/kernel/d2h start and end."""
+        if self._trace is None:
+            return []
+        torch.cuda.synchronize(self.dev)
+        base, out = self._trace["base"], []
+        for r in self._trace["rows"]:
+            if all(k in r for k in ("h0", "h1", "k0", "k1", "d0", "d1")):
+                out.append({k: base.elapsed_time(r[k]) for k in ("h0", "h1", "k0", "k1", "d0", "d1")} | {"frames": r["n"]})
+        return out
 
     def _retire(self, slot):
         if slot["busy"]:
@@ -117,6 +141,8 @@ class BatchPipeline:
             _host_copy(slot["hin_np"][i], frame)     # the decoder-output -> pinned copy
             hsrc = slot["hin"][i]
         with torch.cuda.device(self.dev), torch.cuda.stream(self.s_h2d):
+            if self._trace is not None and i == 0:
+                slot["trow"] = {"h0": self._tev(self.s_h2d)}
             slot["din"][i].copy_(hsrc, non_blocking=True)
 
     def commit(self, slot, n, launch, xf=None):
@@ -130,15 +156,27 @@ class BatchPipeline:
                     slot["dxf"][:n].copy_(slot["hxf"][:n], non_blocking=True)
                     dxf = slot["dxf"][:n]
                 slot["ev_h2d"].record(self.s_h2d)
+                tr = slot.pop("trow", None) if self._trace is not None else None
+                if tr is not None:
+                    tr["h1"] = self._tev(self.s_h2d); tr["n"] = n
             with torch.cuda.stream(self.s_comp):
                 self.s_comp.wait_event(slot["ev_h2d"])
+                if tr is not None:
+                    tr["k0"] = self._tev(self.s_comp)
                 m = int(launch(slot["din"][:n], slot["dout"], dxf))
                 slot["ev_comp"].record(self.s_comp)
+                if tr is not None:
+                    tr["k1"] = self._tev(self.s_comp)
             with torch.cuda.stream(self.s_d2h):
                 self.s_d2h.wait_event(slot["ev_comp"])
+                if tr is not None:
+                    tr["d0"] = self._tev(self.s_d2h)
                 if m:
                     slot["hout"][:m].copy_(slot["dout"][:m], non_blocking=True)
                 slot["ev_d2h"].record(self.s_d2h)
+                if tr is not None:
+                    tr["d1"] = self._tev(self.s_d2h)
+                    self._trace["rows"].append(tr)
             # the next upload into this slot's din / dxf must not overtake this kernel; the next kernel writing dout
             # must not overtake this download: both are ordered by acquire()'s host wait on ev_d2h.
         slot["pending"] = m
@@ -153,6 +191,8 @@ class BatchPipeline:
             if not frames.is_pinned():
                 raise ValueError("a tensor batch must live in pinned host memory")
             with torch.cuda.device(self.dev), torch.cuda.stream(self.s_h2d):
+                if self._trace is not None:
+                    slot["trow"] = {"h0": self._tev(self.s_h2d)}
                 slot["din"][:n].copy_(frames, non_blocking=True)
         else:
             for i, f in enumerate(frames):

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--source", default="pinned", choices=["pinned", "raw", "array"])
     ap.add_argument("--hyperlapse", default="1,1")
+    ap.add_argument("--overlap", action="store_true", help="HIP-event timeline of the three streams during the timed render (printed after the JSON line)")
     args = ap.parse_args()
     preset, w, h, ow, oh, dt = CONFIGS[args.config]
     dev = torch.device("cuda", 0)
@@ -64,6 +65,8 @@ def main():
     st.renderfile(0.0, (min(args.frames, 200) + 1.5) / fps, NullSink(), **kw)          # warm-up: allocations, first-touch, lens table
     torch.cuda.synchronize()
     sink = NullSink()
+    if args.overlap and getattr(st, "_pipe", None) is not None:
+        st._pipe.enable_trace()
     t0 = time.perf_counter()
     n = st.renderfile(0.0, (args.frames + 1.5) / fps, sink, **kw)
     torch.cuda.synchronize()
@@ -75,6 +78,44 @@ def main():
                       "d2h_GBps": n * ow * oh * 3 * esz / dt_s / 1e9,
                       "batch": args.batch or Stabilizer.default_batch(w * h * 3 * esz), "depth": args.depth,
                       "hyperlapse": [mult, nb], "checksum": sink.checksum}))
+    if args.overlap and getattr(st, "_pipe", None) is not None:
+        overlap_report(st._pipe.trace_table())
+
+
+def _inter(a, b):
+    """Total length of the intersection of two lists of disjoint, sorted intervals."""
+    i = j = 0
+    tot = 0.0
+    while i < len(a) and j < len(b):
+        lo, hi = max(a[i][0], b[j][0]), min(a[i][1], b[j][1])
+        if hi > lo:
+            tot += hi - lo
+        if a[i][1] < b[j][1]:
+            i += 1
+        else:
+            j += 1
+    return tot
+
+
+def overlap_report(rows):
+    """rows: BatchPipeline.trace_table().  The upload interval of a batch runs from its first frame's copy to its last (host staging
+    of the frames in between included), so 'H2D' is the time the upload stream is owned by a batch, not pure copy time."""
+    if not rows:
+        print("# no trace rows")
+        return
+    H = [(r["h0"], r["h1"]) for r in rows]; Kk = [(r["k0"], r["k1"]) for r in rows]; Dd = [(r["d0"], r["d1"]) for r in rows]
+    t0, t1 = min(h[0] for h in H), max(d[1] for d in Dd)
+    wall = t1 - t0
+    busy = lambda iv: sum(b - a for a, b in iv)
+    print("# stream timeline from HIP events, %d batches, %.1f ms from the first upload to the last download" % (len(rows), wall))
+    print("#   upload stream busy   %7.1f ms (%3.0f %% of that time)" % (busy(H), 100 * busy(H) / wall))
+    print("#   kernel stream busy   %7.1f ms (%3.0f %%)" % (busy(Kk), 100 * busy(Kk) / wall))
+    print("#   download stream busy %7.1f ms (%3.0f %%)" % (busy(Dd), 100 * busy(Dd) / wall))
+    print("#   upload and download at the same time : %7.1f ms (%3.0f %% of the download time)" % (_inter(H, Dd), 100 * _inter(H, Dd) / max(busy(Dd), 1e-9)))
+    print("#   kernel while an upload is in progress : %7.1f ms (%3.0f %% of the kernel time)" % (_inter(Kk, H), 100 * _inter(Kk, H) / max(busy(Kk), 1e-9)))
+    print("#   kernel while a download is in progress: %7.1f ms (%3.0f %% of the kernel time)" % (_inter(Kk, Dd), 100 * _inter(Kk, Dd) / max(busy(Kk), 1e-9)))
+    print("#   sum of the three busy times / wall    : %.2f (1.0 = nothing overlaps, 3.0 = everything does)" % ((busy(H) + busy(Kk) + busy(Dd)) / wall))
+    print("#   first batches (ms): " + "; ".join("H %.1f-%.1f K %.1f-%.1f D %.1f-%.1f" % (r["h0"] - t0, r["h1"] - t0, r["k0"] - t0, r["k1"] - t0, r["d0"] - t0, r["d1"] - t0) for r in rows[:4]))
 
 
 if __name__ == "__main__":
