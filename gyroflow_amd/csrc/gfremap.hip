@@ -1491,7 +1491,8 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, cons
 }
 
 // K1b: fused + hyperlapse blend: out = trunc(sum_b (1/N) * remap_b) in float64, reference order.
-template <int DEPTH, int BORDER>
+// POW2 (n_blend a power of two): integer sum and shift, exactly the float64 result -- see k_undistort_rotate_blend_rp.
+template <int DEPTH, int BORDER, bool POW2>
 __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens,
                                                                    LensK lk, int frames_per_group, int n_blend)
 {
@@ -1504,13 +1505,15 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, c
     const int x0 = tx*TILE_W + lx*PXT;
     if (x0 >= A.dw) return;
     const double wgt = 1.0/(double)n_blend;       // Python: 1/(self.hyperlapse_num_blended_frames)
+    const int shift = 31 - __builtin_clz((unsigned)n_blend);      // log2(n_blend) when POW2
+    typedef typename std::conditional<POW2, unsigned, double>::type AccT;
 #pragma unroll 1
     for (int pass = 0; pass < TILE_H/PASS_H; pass++) {
         const int y = ty*TILE_H + pass*PASS_H + ly;
         if (y >= A.dh) break;
-        double acc[PXT][3];
+        AccT acc[PXT][3];
 #pragma unroll
-        for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0.0;
+        for (int i = 0; i < PXT; i++) acc[i][0] = acc[i][1] = acc[i][2] = 0;
 #pragma unroll 1
         for (int b = 0; b < n_blend; b++) {
             const int frame = g*frames_per_group + b;
@@ -1524,13 +1527,19 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend(RemapArgs A, c
 #pragma unroll
             for (int i = 0; i < PXT; i++)
 #pragma unroll
-                for (int c = 0; c < 3; c++) acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[i][c]));
+                for (int c = 0; c < 3; c++) {
+                    if constexpr (POW2) acc[i][c] += (unsigned)o[i][c];
+                    else                acc[i][c] = __dadd_rn(acc[i][c], __dmul_rn(wgt, (double)o[i][c]));
+                }
         }
         int px[PXT][3];
 #pragma unroll
         for (int i = 0; i < PXT; i++)
 #pragma unroll
-            for (int c = 0; c < 3; c++) px[i][c] = (int)acc[i][c];      // astype(uint): truncation
+            for (int c = 0; c < 3; c++) {
+                if constexpr (POW2) px[i][c] = (int)(acc[i][c] >> shift);
+                else                px[i][c] = (int)acc[i][c];          // astype(uint): truncation
+            }
         uint8_t* drow = A.dst + (size_t)g*A.dframe + (size_t)y*A.dstep;
         store_px<DEPTH>(drow, x0, A.dw, px, 0u, A.dst_vec_ok);
     }
@@ -3106,13 +3115,11 @@ GF_API int gf_undistort_rotate_blend_c3(void* ctx, int depth, const void* src, i
         return GF_OK;
     }
     dim3 grid(A.tiles_x*A.tiles_y, n_out);
-    if (depth == GF_DEPTH_U8) {
-        if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
-        else                              hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U8, GF_BORDER_REPLICATE>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
-    } else {
-        if (border == GF_BORDER_CONSTANT) hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U16, GF_BORDER_CONSTANT>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
-        else                              hipLaunchKernelGGL((k_undistort_rotate_blend<GF_DEPTH_U16, GF_BORDER_REPLICATE>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend);
-    }
+#define LAUNCH_BL(DEPTH_, BORDER_) do { if ((n_blend & (n_blend - 1)) == 0) hipLaunchKernelGGL((k_undistort_rotate_blend<DEPTH_, BORDER_, true>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend); \
+                                         else hipLaunchKernelGGL((k_undistort_rotate_blend<DEPTH_, BORDER_, false>), grid, dim3(BLOCK), 0, (hipStream_t)stream, A, (const Xf*)xf_dev, lens, lk, frames_per_group, n_blend); } while (0)
+    if (depth == GF_DEPTH_U8) { if (border == GF_BORDER_CONSTANT) LAUNCH_BL(GF_DEPTH_U8, GF_BORDER_CONSTANT); else LAUNCH_BL(GF_DEPTH_U8, GF_BORDER_REPLICATE); }
+    else                      { if (border == GF_BORDER_CONSTANT) LAUNCH_BL(GF_DEPTH_U16, GF_BORDER_CONSTANT); else LAUNCH_BL(GF_DEPTH_U16, GF_BORDER_REPLICATE); }
+#undef LAUNCH_BL
     HIP_TRY(hipGetLastError());
     return GF_OK;
 }
