@@ -54,52 +54,44 @@ class FisheyeCalibrator:
                 round(new_img_dim[1] * self.calib_dimension[1] / self.orig_dimension[1]))
 
     # ------------------------------------------------------------------ presets (:520-587, :642-652)
+    # Descriptive preset fields copied into extra_cam_info: (key, default); None = the field is taken as it is (may be absent).
+    _INFO_FIELDS = (("note", None), ("calibrated_by", "N/A"), ("camera_brand", "N/A"), ("camera_model", "N/A"),
+                    ("camera_setting", "N/A"), ("lens_model", "N/A"), ("calibrator_version", None), ("date", None))
+
     def load_calibration_data(self, cal_data, printinfo=False):
-        try:
-            if not cal_data["use_opencv_fisheye"]:
-                raise Exception("Preset not for OpenCV fisheye lens model")
-            self.data_from_preset_file = True
-            if printinfo:
-                print("Preset name: {}".format(cal_data["name"]))
-                print("Note: {}".format(cal_data["note"]))
-                print("Made with {} frames using calibrator version {} on date {}".format(
-                    cal_data["num_images"], cal_data["calibrator_version"], cal_data["date"]))
-            if cal_data["calibrator_version"] != __version__ and printinfo:
+        """Take K, D and the calibration / original frame sizes from a preset dictionary (the JSON schema of
+        calibrate_video.py:483-518 as read at :520-587); returns the descriptive fields as extra_cam_info."""
+        if not cal_data["use_opencv_fisheye"]:
+            raise Exception("Preset not for OpenCV fisheye lens model")
+        wh = lambda d: (d["w"], d["h"])
+        lens = cal_data["fisheye_params"]
+        self.data_from_preset_file = True
+        self.calib_dimension = wh(cal_data["calib_dimension"])
+        stretched = "orig_dimension" in cal_data                         # preset format >= 0.3.0
+        self.orig_dimension = wh(cal_data["orig_dimension"]) if stretched else self.calib_dimension
+        self.input_horizontal_stretch = cal_data["input_horizontal_stretch"] if stretched else 1
+        self.K = np.array(lens["camera_matrix"])
+        self.D = np.array(lens["distortion_coeffs"])
+        self.RMS_error = lens["RMS_error"]
+        self.num_images = self.num_images_used = cal_data["num_images"]
+
+        info = {"name": " ".join(cal_data.get("name").replace("_", " ").split())}
+        for key, default in self._INFO_FIELDS:
+            info[key] = cal_data.get(key) if default is None else cal_data.get(key, default)
+        ow, oh = self.orig_dimension
+        if oh == 0:
+            raise KeyError("Error loading preset file")
+        info.update(width=ow, height=oh, aspect=ow / oh, num_images=self.num_images)
+        self.extra_cam_info = info
+        if printinfo:
+            print("Preset name: {}".format(cal_data["name"]))
+            print("Note: {}".format(cal_data["note"]))
+            print("Made with {} frames using calibrator version {} on date {}".format(
+                cal_data["num_images"], cal_data["calibrator_version"], cal_data["date"]))
+            if cal_data["calibrator_version"] != __version__:
                 print("Note: Versions don't match. Calibrator: {}, Preset: {}. Should be fine though.".format(
                     __version__, cal_data["calibrator_version"]))
-
-            self.calib_dimension = (cal_data["calib_dimension"]["w"], cal_data["calib_dimension"]["h"])
-            if "orig_dimension" in cal_data:      # added in preset format 0.3.0
-                self.input_horizontal_stretch = cal_data["input_horizontal_stretch"]
-                self.orig_dimension = (cal_data["orig_dimension"]["w"], cal_data["orig_dimension"]["h"])
-            else:
-                self.input_horizontal_stretch = 1
-                self.orig_dimension = self.calib_dimension
-
-            self.num_images = self.num_images_used = cal_data["num_images"]
-            self.RMS_error = cal_data["fisheye_params"]["RMS_error"]
-            self.K = np.array(cal_data["fisheye_params"]["camera_matrix"])
-            self.D = np.array(cal_data["fisheye_params"]["distortion_coeffs"])
-
-            fixed_name = " ".join(cal_data.get("name").replace("_", " ").split())
-            self.extra_cam_info = {
-                "name": fixed_name,
-                "note": cal_data.get("note"),
-                "calibrated_by": cal_data.get("calibrated_by", "N/A"),
-                "camera_brand": cal_data.get("camera_brand", "N/A"),
-                "camera_model": cal_data.get("camera_model", "N/A"),
-                "camera_setting": cal_data.get("camera_setting", "N/A"),
-                "lens_model": cal_data.get("lens_model", "N/A"),
-                "calibrator_version": cal_data.get("calibrator_version"),
-                "date": cal_data.get("date"),
-                "width": self.orig_dimension[0],
-                "height": self.orig_dimension[1],
-                "aspect": self.orig_dimension[0] / self.orig_dimension[1],
-                "num_images": self.num_images,
-            }
-        except ZeroDivisionError:
-            raise KeyError("Error loading preset file")
-        return self.extra_cam_info
+        return info
 
     def get_calibration_data(self):
         """Preset dictionary in the reference's format (calibrate_video.py:483-518)."""
