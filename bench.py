@@ -4,6 +4,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--config c3] [--batch B] [--scaling weak|strong] [--mode m1|m2]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) makes this process the launcher: before touching any device
+it starts N fresh ranks of itself, one per GPU (gloo rendezvous on 127.0.0.1), and exits with their status; it refuses to run
+with fewer GPUs than asked (exit 2) rather than print a line for another configuration.
+
 Default (what the driver runs): mode M1 of BASELINE.md, weak scaling.  A step = one launch of the fused kernel
 (gf_undistort_rotate_c3; c5: gf_undistort_rotate_blend_c3 with set_hyperlapse(4, 4); c4: the fused remap + superview
 stretch) over one batch of B synthetic frames that are already resident in HBM; every frame of every step uses its own
@@ -196,20 +200,55 @@ def main():
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--mode", default="m1", choices=["m1", "m2"])
     ap.add_argument("--no-pcie", action="store_true", help="skip the pcie_pipeline leg")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than GPUs (ranks share devices: a rehearsal of the launch path, not a scaling number)")
+    ap.add_argument("--dry-run", action="store_true", help="start the ranks, meet in the gloo group, print the rank map and exit (no GPU work)")
     args = ap.parse_args()
 
-    import torch
     from gyroflow_amd import dist as gdist
 
-    rank, local_rank, world = gdist.init_from_env()      # gloo: timing barrier only; no data-path collective
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # No launcher around us: this process becomes the launcher.  It starts one fresh rank per GPU BEFORE anything here
+        # has touched a device (torch.cuda.device_count() does not initialise one) and never computes itself.
+        import torch
+        n_dev = 0 if args.dry_run else torch.cuda.device_count()
+        if not args.dry_run and n_dev < args.gpus and not args.oversubscribe:
+            print("bench.py: --gpus %d but %d GPU(s) visible; refusing to print a line for fewer GPUs than asked "
+                  "(--oversubscribe rehearses the launch path with ranks sharing devices)" % (args.gpus, n_dev), file=sys.stderr)
+            sys.exit(2)
+        sys.exit(gdist.launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
 
+    if args.gpus != int(os.environ.get("WORLD_SIZE", "1")):
+        # a launcher's WORLD_SIZE and --gpus disagree: the line would carry an n_gpus nobody asked for (checked before the
+        # rendezvous, which would wait for ranks that do not exist)
+        if os.environ.get("RANK", "0") == "0":
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE %s ranks" % (args.gpus, os.environ.get("WORLD_SIZE")), file=sys.stderr)
+        sys.exit(2)
+    rank, local_rank, world = gdist.init_from_env()      # gloo: timing barrier only; no data-path collective
+    if args.dry_run:
+        gdist.barrier()
+        ranks = gdist.sum_over_ranks(1.0)
+        top = gdist.max_over_ranks(float(rank))
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_met": int(ranks), "max_rank": int(top)}), flush=True)
+        gdist.shutdown()
+        return
+
+    import torch
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    dev_index = local_rank % torch.cuda.device_count()
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not args.oversubscribe:
+        if rank == 0:
+            print("bench.py: %d ranks but %d GPU(s) visible (--oversubscribe lets ranks share devices)" % (world, n_dev), file=sys.stderr)
+        gdist.shutdown()
+        sys.exit(2)
+    dev_index = local_rank % n_dev
+    # one worker per GPU, on the CPUs next to it -- before torch.cuda / HIP start their own threads, so those inherit the mask
+    pinned_cpus = gdist.pin_to_gpu(dev_index) if world > 1 or args.mode == "m2" else None
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
-    pinned_cpus = gdist.pin_to_gpu(dev_index) if world > 1 or args.mode == "m2" else None     # one worker per GPU, next to it
 
     from gyroflow_amd import cv, FisheyeCalibrator, synthetic_frames
     from gyroflow_amd.stabilizer import frame_shard
@@ -333,7 +372,8 @@ def main():
                                    "GX016015.MP4.gyroflow trace, preset %s" % (B, args.border, preset),
                        "frames_per_step": units_per_step if args.scaling == "strong" else B // nb, "output_frames_per_step_all_gpus": units_per_step,
                        "sharding": "contiguous frame ranges (frame_shard), no collective",
-                       "cpu_affinity": sorted(pinned_cpus) if pinned_cpus else None},
+                       "cpu_affinity": sorted(pinned_cpus) if pinned_cpus else None,     # every thread of rank 0 (dist.pin_to_gpu)
+                       "gpus_visible": n_dev},
             "checksum": checksum,
         }
         if nb > 1:

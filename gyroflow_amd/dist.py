@@ -83,6 +83,17 @@ def pin_to_numa_node(node, sysfs="/sys"):
         allowed = cpus & os.sched_getaffinity(0)
         if not allowed:
             return None
+        # sched_setaffinity(0, ...) moves the calling thread only: threads that already exist (HIP runtime, OpenMP, torch's
+        # pools) keep their mask, so every task of the process is moved; threads created later inherit from their creator
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = []
+        for tid in tids:
+            try:
+                os.sched_setaffinity(tid, allowed)
+            except OSError:          # a thread that exited meanwhile
+                pass
         os.sched_setaffinity(0, allowed)
         return allowed
     except (OSError, ValueError):
@@ -91,5 +102,48 @@ def pin_to_numa_node(node, sysfs="/sys"):
 
 def pin_to_gpu(device_index):
     """One worker per GPU, on the CPUs next to it: the host side of a sharded render is bound by PCIe and host DRAM, so the
-    pinned ring and the copy threads should live on the GPU's own NUMA node.  No-op where the platform does not say."""
+    pinned ring and the copy threads should live on the GPU's own NUMA node.  Every thread the process has at the time of
+    the call is moved (call it before the pinned ring and the copy pool are created).  No-op where the platform does not say."""
     return pin_to_numa_node(gpu_numa_node(device_index))
+
+
+def free_port():
+    """A TCP port that is free on 127.0.0.1 right now (for the rendezvous of ranks this process is about to start)."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(argv, world, extra_env=None, poll_s=0.2):
+    """Start `world` fresh processes `argv` (one rank each: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment),
+    wait for all of them and return the largest exit code.  When one rank fails the others are stopped (by their own PIDs), so
+    nobody is left waiting in a barrier.  The caller must not have touched the GPU: the children own the devices."""
+    import subprocess
+    import time
+    port = free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), **(extra_env or {}))
+        procs.append(subprocess.Popen(argv, env=env))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+            if bad:
+                rc = bad[0]
+                break
+            time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                if rc:
+                    p.terminate()
+                try:
+                    p.wait(timeout=30 if rc else None)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+    codes = [p.returncode for p in procs]
+    return max([abs(c) for c in codes] + [abs(rc)])

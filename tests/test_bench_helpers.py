@@ -34,3 +34,34 @@ def test_touched_footprint_is_bounded_and_sensible(orc):
     # identity rotation, same call: the footprint is symmetric about the frame centre, so it cannot exceed the frame either
     t0 = bench.touched_source_bytes("c2", cal, np.array([[1.0, 0, 0, 0]]), [0])
     assert 0.2 * full < t0 <= full
+
+
+def _run_bench(args, env=None, timeout=180):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def test_gpus_n_without_launcher_spawns_n_ranks():
+    """`bench.py --gpus 2` with no launcher around it starts two ranks itself (gloo on 127.0.0.1); --dry-run makes them meet,
+    print the rank map and leave without touching a device.  It must never print an n_gpus: 1 line for --gpus 2."""
+    import json
+    r = _run_bench(["--gpus", "2", "--dry-run"])
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"dry_run": True, "n_gpus": 2, "ranks_met": 2, "max_rank": 1}]
+
+
+def test_gpus_n_refuses_when_the_gpus_are_not_there():
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("needs a host with fewer than two GPUs")
+    r = _run_bench(["--gpus", "2"])
+    assert r.returncode == 2 and "n_gpus" not in r.stdout and "refusing" in r.stderr
+
+
+def test_launcher_world_size_must_match_gpus():
+    r = _run_bench(["--gpus", "4", "--dry-run"], env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, timeout=60)
+    assert r.returncode == 2 and "WORLD_SIZE 2" in r.stderr and r.stdout.strip() == ""
