@@ -49,6 +49,8 @@ SIGNATURES = {
     "gf_remap_cubic_u8c3_f32maps": [_vp, _vp, _i, _i, _sz, _vp, _i, _i, _sz, _vp, _sz, _vp, _sz, _i, _dp, _vp],
     "gf_superview_cubic_u8c3": [_vp, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _vp, _vp, _i, _i, _dp, _vp],
     "gf_undistort_rotate_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _dp, _vp],
+    "gf_rotate_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _sz, _sz, _i, _i, _vp],
+    "gf_undistort_rotate_rot_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _i, _dp, _vp],
     "gf_undistort_rotate_stretched_c3": [_vp, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _f, _f, _f, _f, _i, _dp, _vp],
     "gf_undistort_rotate_superview_u8c3": [_vp, _vp, _i, _i, _sz, _sz, _i, _i, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _vp, _vp, _i, _dp, _vp],
     "gf_undistort_rotate_c3_noalloc": [_i, _i, _vp, _i, _i, _sz, _sz, _vp, _i, _i, _sz, _sz, _dp, _vp, _i, _i, _dp, _vp],

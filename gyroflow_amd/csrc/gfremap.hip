@@ -525,13 +525,35 @@ template <int DEPTH> struct PixT;
 template <> struct PixT<GF_DEPTH_U8>  { typedef uint8_t  T; };
 template <> struct PixT<GF_DEPTH_U16> { typedef uint16_t T; };
 
+// cv2.rotate(frame, code) of the render loop (stabilizer.py:1385-1386) folded into the tap addressing: the kernel remaps the
+// ROTATED frame (SrcImg.w / .h are its size) without ever building it.  With p the rotated coordinate that runs along the
+// stored frame's rows (x, or y for the 90 degree codes) and q the other one, rotated pixel (x, y) is stored pixel
+// (column cs > 0 ? p : stw - 1 - p, row rs > 0 ? q : sth - 1 - q).
+struct RotMap {
+    int swap;              // 90 degree codes: the rotated x axis runs along the stored frame's columns (down or up a column)
+    int cs, rs;            // +1 / -1: direction of p along a stored row, of q down a stored column
+    int stw, sth;          // stored frame size
+};
+struct NoRot {};
+template <bool ROT> struct RotT;
+template <> struct RotT<false> { typedef NoRot T; };
+template <> struct RotT<true>  { typedef RotMap T; };
+
+__device__ __forceinline__ unsigned rot_pixel_offset(const SrcImg& s, const NoRot&, int x, int y, int esz) { return (unsigned)y*s.step + (unsigned)(x*3*esz); }
+__device__ __forceinline__ unsigned rot_pixel_offset(const SrcImg& s, const RotMap& m, int x, int y, int esz)
+{
+    const int p = m.swap ? y : x, q = m.swap ? x : y;
+    const int col = m.cs > 0 ? p : m.stw - 1 - p, row = m.rs > 0 ? q : m.sth - 1 - q;
+    return (unsigned)row*s.step + (unsigned)(col*3*esz);
+}
+
 // One bilinear output pixel, cv::remapBilinear semantics (imgwarp.cpp), any border case.  (sx, sy) are the map's
 // int16 coordinates, a = fy*32 + fx.  Returns false when the pixel must be left untouched (BORDER_TRANSPARENT
 // outside).  This is the general (slow) path; interior pixels go through interp_u8_interior / interp_u16_interior.
 struct Px3 { int c0, c1, c2, ok; };
 
-template <int DEPTH, int BORDER>
-__device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0, int cv1, int cv2)
+template <int DEPTH, int BORDER, class ROTM = NoRot>
+__device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0, int cv1, int cv2, ROTM rm = ROTM())
 {
     typedef typename PixT<DEPTH>::T T;
     const int cval[3] = {cv0, cv1, cv2};
@@ -560,7 +582,7 @@ __device__ __noinline__ Px3 bilinear_px(SrcImg s, int sx, int sy, int a, int cv0
 #pragma unroll
     for (int t = 0; t < 4; t++) {
         if (vs[t]) {
-            const T* q = (const T*)(s.base + (size_t)ys[t]*s.step) + xs[t]*3;
+            const T* q = (const T*)(s.base + rot_pixel_offset(s, rm, xs[t], ys[t], (int)sizeof(T)));
             p[t][0] = q[0]; p[t][1] = q[1]; p[t][2] = q[2];
         } else {
             p[t][0] = cval[0]; p[t][1] = cval[1]; p[t][2] = cval[2];
@@ -608,10 +630,21 @@ __device__ __forceinline__ unsigned umad24(unsigned a, unsigned b, unsigned c)
 //   ((sum + 512) >> 10) & 255  ==  OpenCV's (sum(S * w_q15) + 2^14) >> 15   (its Q15 weights are 32 wy wx).
 // HI16 = true leaves the result in byte 2 (store_px picks it up with v_perm_b32), false shifts it down.
 template <bool HI16>
+__device__ __forceinline__ void bilin_u8_weights(uint64_t ta, uint64_t tb, unsigned wx, unsigned wy1, int* out);
+
+template <bool HI16>
 __device__ __forceinline__ void bilin_u8_rows(uint64_t ta, uint64_t tb, unsigned iu, unsigned iv, int* out)
 {
     const unsigned wx = __umul24(iu & 31u, 0xFFFFFFu) + 32u;               // (32 - fx) | fx << 24
-    const unsigned wy1 = (iv << 6) & 0x7C0u, wy0 = 2048u - wy1;             // 64 fy, 64 (32 - fy)
+    const unsigned wy1 = (iv << 6) & 0x7C0u;                                // 64 fy
+    bilin_u8_weights<HI16>(ta, tb, wx, wy1, out);
+}
+
+// wx = (weight of the left pixel) | (weight of the right pixel) << 24, wy1 = 64 * (weight of the lower row); weights 0 .. 32.
+template <bool HI16>
+__device__ __forceinline__ void bilin_u8_weights(uint64_t ta, uint64_t tb, unsigned wx, unsigned wy1, int* out)
+{
+    const unsigned wy0 = 2048u - wy1;                                       // 64 (32 - fy)
     const uint32_t a0 = (uint32_t)ta, a1 = (uint32_t)(ta >> 8), a2 = (uint32_t)(ta >> 16);
     const uint32_t b0 = (uint32_t)tb, b1 = (uint32_t)(tb >> 8), b2 = (uint32_t)(tb >> 16);
     const unsigned tB = __builtin_amdgcn_udot4(a0, wx, 0u, false), tG = __builtin_amdgcn_udot4(a1, wx, 0u, false), tR = __builtin_amdgcn_udot4(a2, wx, 0u, false);
@@ -751,6 +784,74 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
             const int sx = (int)(int16_t)(iu[i] >> INTER_BITS), sy = (int)(int16_t)(iv[i] >> INTER_BITS);   // Q1: wrapping cast
             const int a = (iv[i] & 31)*32 + (iu[i] & 31);
             const Px3 o = bilinear_px<DEPTH, BORDER>(s, sx, sy, a, cval[0], cval[1], cval[2]);
+            if (!o.ok) keep |= 1u << i;
+            px[i][0] = HI16 ? o.c0 << 16 : o.c0; px[i][1] = HI16 ? o.c1 << 16 : o.c1; px[i][2] = HI16 ? o.c2 << 16 : o.c2;
+        }
+    }
+    return keep;
+}
+
+// remap4 on a frame that cv2.rotate would have turned first (RotMap).  Interior pixels: the 2 x 2 taps of the rotated frame are
+// a 2 x 2 block of the stored frame -- left column (p, or stw - 2 - p when p runs right to left), upper row likewise -- so the
+// same aligned loads serve, with the horizontal / vertical weights taken from the fraction of whichever rotated axis runs
+// along the stored rows / columns and mirrored where the axis is reversed.  u8: the weighted sum is the same set of integer
+// products, so the result is bit-identical to remapping the rotated copy.  u16: OpenCV sums the four float products in the
+// rotated frame's tap order, which is kept here by permuting the taps.  Everything else takes the general path, whose border
+// decisions are made on the rotated coordinates and whose pixel fetch goes through rot_pixel_offset.
+template <int DEPTH, int BORDER, bool HI16 = false>
+__device__ __forceinline__ unsigned remap4_rot(const SrcImg& s, const RotMap& m, const int* iu, const int* iv, const int* cval, int (*px)[3])
+{
+    static_assert(PXT == 4, "interior test is written for 4 pixels");
+    unsigned keep = 0;
+    int ip[PXT], iq[PXT];
+#pragma unroll
+    for (int i = 0; i < PXT; i++) { ip[i] = m.swap ? iv[i] : iu[i]; iq[i] = m.swap ? iu[i] : iv[i]; }
+    const int pmin = min(min(ip[0], ip[1]), min(ip[2], ip[3])), pmax = max(max(ip[0], ip[1]), max(ip[2], ip[3]));
+    const int qmin = min(min(iq[0], iq[1]), min(iq[2], iq[3])), qmax = max(max(iq[0], iq[1]), max(iq[2], iq[3]));
+    // the aligned 12-byte (u8) / 16-byte (u16) loads need their left column <= stw - 4 (see remap4); rows 0 .. sth - 2
+    const int plo = m.cs > 0 ? 0 : 2, phi = m.cs > 0 ? m.stw - 4 : m.stw - 2;
+    if (pmin >= (plo << INTER_BITS) && pmax < ((phi + 1) << INTER_BITS) && qmin >= 0 && qmax < ((m.sth - 1) << INTER_BITS)) {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const unsigned sp = (unsigned)ip[i] >> INTER_BITS, sq = (unsigned)iq[i] >> INTER_BITS, fp = (unsigned)ip[i] & 31u, fq = (unsigned)iq[i] & 31u;
+            const unsigned col = m.cs > 0 ? sp : (unsigned)(m.stw - 2) - sp, row = m.rs > 0 ? sq : (unsigned)(m.sth - 2) - sq;
+            if constexpr (DEPTH == GF_DEPTH_U8) {
+                const unsigned hx = m.cs > 0 ? fp : 32u - fp, vy = m.rs > 0 ? fq : 32u - fq;      // weight of the right pixel / the lower row
+                const TapsU8 t = fetch_u8_interior(s.base, s.step, col << INTER_BITS, row << INTER_BITS);
+                bilin_u8_weights<HI16>(t.a, t.b, __umul24(hx, 0xFFFFFFu) + 32u, vy << 6, px[i]);
+            } else {
+                const TapsU16 t = fetch_u16_interior(s.base, s.step, col << INTER_BITS, row << INTER_BITS);
+                // T[r][c]: stored block, r = upper / lower row, c = left / right pixel
+                unsigned T[2][2][3] = {{{t.a.a & 0xffff, t.a.a >> 16, t.a.b & 0xffff}, {t.a.b >> 16, t.a.c & 0xffff, t.a.c >> 16}},
+                                       {{t.b.a & 0xffff, t.b.a >> 16, t.b.b & 0xffff}, {t.b.b >> 16, t.b.c & 0xffff, t.b.c >> 16}}};
+                // rotated tap (i along x, j along y) sits at p-step tp = swap ? j : i and q-step tq = swap ? i : j, i.e. stored column
+                // c = cs > 0 ? tp : 1 - tp and stored row r = rs > 0 ? tq : 1 - tq
+                unsigned P[2][2][3];            // [j][i]
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ii++)
+#pragma unroll
+                        for (int ch = 0; ch < 3; ch++) {
+                            const unsigned a00 = T[0][0][ch], a01 = T[0][1][ch], a10 = T[1][0][ch], a11 = T[1][1][ch];
+                            // value at (tq, tp) for both choices of swap, then the mirrorings
+                            const int tp0 = ii, tq0 = j, tp1 = j, tq1 = ii;
+                            auto pick = [&](int tq, int tp) -> unsigned {
+                                const unsigned up = m.cs > 0 ? (tp ? a01 : a00) : (tp ? a00 : a01);     // stored upper row, column by tp
+                                const unsigned lo = m.cs > 0 ? (tp ? a11 : a10) : (tp ? a10 : a11);
+                                return m.rs > 0 ? (tq ? lo : up) : (tq ? up : lo);
+                            };
+                            P[j][ii][ch] = m.swap ? pick(tq1, tp1) : pick(tq0, tp0);
+                        }
+                bilin_u16_vals(P[0][0], P[0][1], P[1][0], P[1][1], iu[i] & 31, iv[i] & 31, px[i]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < PXT; i++) {
+            const int sx = (int)(int16_t)(iu[i] >> INTER_BITS), sy = (int)(int16_t)(iv[i] >> INTER_BITS);   // Q1: wrapping cast
+            const int a = (iv[i] & 31)*32 + (iu[i] & 31);
+            const Px3 o = bilinear_px<DEPTH, BORDER, RotMap>(s, sx, sy, a, cval[0], cval[1], cval[2], m);
             if (!o.ok) keep |= 1u << i;
             px[i][0] = HI16 ? o.c0 << 16 : o.c0; px[i][1] = HI16 ? o.c1 << 16 : o.c1; px[i][2] = HI16 ? o.c2 << 16 : o.c2;
         }
@@ -1232,9 +1333,10 @@ __device__ __forceinline__ void interp_u8_raw(const uint32_t* box, unsigned ru, 
 __device__ unsigned long long g_wg_trace[8192][3];
 #endif
 
-template <int DEPTH, int BORDER>
+template <int DEPTH, int BORDER, bool ROT = false>
 __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
-                                                                const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work)
+                                                                const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work,
+                                                                typename RotT<ROT>::T rot)
 {
     __shared__ double2 s_tab[LENS_DOUBLES/2];
     __shared__ RpShared S;
@@ -1303,7 +1405,9 @@ __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(Rema
 #else
                     else coord_q5x4(row_consts(xf, y), xf, lk, lens_hi_limit(xf, lk), s_tab, x0, iu, iv);
 #endif
-                    const unsigned keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
+                    unsigned keep;
+                    if constexpr (ROT) keep = remap4_rot<DEPTH, BORDER, HI16>(s, rot, iu, iv, A.cval, px);       // A.sw, A.sh: the rotated frame's size
+                    else               keep = remap4<DEPTH, BORDER, HI16>(s, iu, iv, A.cval, px);
                     uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
                     store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
                 }
@@ -2286,6 +2390,20 @@ __global__ void __launch_bounds__(BLOCK, 4) k_undistort_rotate_superview(RemapAr
     }
 }
 
+// cv2.rotate (90 degrees clockwise, 180, 90 counter-clockwise) of a batch of frames: the unfused form of what
+// k_undistort_rotate_rp<.., true> does in its tap addressing, for the kernels that have no rotated form.
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_rotate_c3(const uint8_t* __restrict__ src, unsigned sstep, size_t sframe, uint8_t* __restrict__ dst, int dw, int dh,
+                                                     size_t dstep, size_t dframe, RotMap m)
+{
+    const int x = blockIdx.x*64 + (threadIdx.x & 63), y = blockIdx.y*4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    const SrcImg s{src + (size_t)blockIdx.z*sframe, dw, dh, sstep};
+    const T* q = (const T*)(s.base + rot_pixel_offset(s, m, x, y, (int)sizeof(T)));
+    T* d = (T*)(dst + (size_t)blockIdx.z*dframe + (size_t)y*dstep) + x*3;
+    d[0] = q[0]; d[1] = q[1]; d[2] = q[2];
+}
+
 // K6: hyperlapse blend passes (unfused form).
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_blend_acc(const T* __restrict__ f, double* acc, double wgt, int reset, size_t n)
@@ -2853,9 +2971,12 @@ struct FusedEnv { int k1_mode; int n_cu; const double* rp_tab; };
 static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
                         void* dst, int dw, int dh, size_t dstep, size_t dframe, const double* lens, LensK lk,
                         const gf_frame_xform* xf_dev, int n_frames, int border, const double* bv, hipStream_t stream,
-                        const float* stretch = nullptr)
+                        const float* stretch = nullptr, const RotMap* rot = nullptr)
 {
-    RemapArgs A = make_args(depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
+    // with `rot`, sw x sh is the stored frame and the kernel sees the frame cv2.rotate would have made of it
+    if (rot && (c->k1_mode != GF_KERNEL_RP || stretch))
+        return fail(GF_ERR_UNSUPPORTED, "%s: the rotated-source form runs on the RP kernel only (rotate with gf_rotate_c3 first)", "gf_undistort_rotate_rot_c3");
+    RemapArgs A = make_args(depth, src, rot && rot->swap ? sh : sw, rot && rot->swap ? sw : sh, sstep, sframe, dst, dw, dh, dstep, dframe, bv);
     if (stretch && !(stretch[0] == 1.f && stretch[1] == 1.f && stretch[2] == 1.f && stretch[3] == 1.f)) {
         A.stretch_on = 1; A.sxn = stretch[0]; A.sxd = stretch[1]; A.syn = stretch[2]; A.syd = stretch[3];
     }
@@ -2882,7 +3003,14 @@ static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, i
             else if (border == GF_BORDER_REPLICATE) hipLaunchKernelGGL((k_undistort_rotate_rl<GF_BORDER_REPLICATE>), grid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
             else                                    hipLaunchKernelGGL((k_undistort_rotate_rl<GF_BORDER_TRANSPARENT>), grid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
         } else {
-            DISPATCH_DEPTH_BORDER(k_undistort_rotate_rp, depth, border, grid, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
+            if (rot) {
+#define LAUNCH_ROT(DEPTH_, BORDER_) hipLaunchKernelGGL((k_undistort_rotate_rp<DEPTH_, BORDER_, true>), grid, dim3(BLOCK), 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work, *rot)
+                if (depth == GF_DEPTH_U8) { if (border == GF_BORDER_CONSTANT) LAUNCH_ROT(GF_DEPTH_U8, GF_BORDER_CONSTANT); else if (border == GF_BORDER_REPLICATE) LAUNCH_ROT(GF_DEPTH_U8, GF_BORDER_REPLICATE); else LAUNCH_ROT(GF_DEPTH_U8, GF_BORDER_TRANSPARENT); }
+                else                      { if (border == GF_BORDER_CONSTANT) LAUNCH_ROT(GF_DEPTH_U16, GF_BORDER_CONSTANT); else if (border == GF_BORDER_REPLICATE) LAUNCH_ROT(GF_DEPTH_U16, GF_BORDER_REPLICATE); else LAUNCH_ROT(GF_DEPTH_U16, GF_BORDER_TRANSPARENT); }
+#undef LAUNCH_ROT
+            } else {
+                DISPATCH_DEPTH_BORDER(k_undistort_rotate_rp, depth, border, grid, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work, NoRot());
+            }
         }
     } else {
         // persistent grid: WG_PER_CU workgroups per CU (what the kernel's register and LDS use allows), a multiple of 8
@@ -2924,6 +3052,57 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
     const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
     return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
                         border, bv, (hipStream_t)stream);
+}
+
+static int rot_map_from_code(const char* fn, int code, int sw, int sh, RotMap* m)
+{
+    m->stw = sw; m->sth = sh;
+    if (code == GF_ROTATE_90_CLOCKWISE)             { m->swap = 1; m->cs = 1;  m->rs = -1; }     // R[y][x] = S[sh-1-x][y]
+    else if (code == GF_ROTATE_180)                 { m->swap = 0; m->cs = -1; m->rs = -1; }     // R[y][x] = S[sh-1-y][sw-1-x]
+    else if (code == GF_ROTATE_90_COUNTERCLOCKWISE) { m->swap = 1; m->cs = -1; m->rs = 1; }      // R[y][x] = S[x][sw-1-y]
+    else return fail(GF_ERR_INVALID_ARG, "%s: rotate code %lld is not one of cv2.ROTATE_90_CLOCKWISE (0), ROTATE_180 (1), ROTATE_90_COUNTERCLOCKWISE (2)", fn, code);
+    return GF_OK;
+}
+
+GF_API int gf_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                        void* dst, size_t dstep, size_t dframe, int n_frames, int rotate_code, gf_stream_t stream)
+{
+    const char* fn = "gf_rotate_c3";
+    RotMap m;
+    int rc = rot_map_from_code(fn, rotate_code, sw, sh, &m); if (rc) return rc;
+    const int dw = m.swap ? sh : sw, dh = m.swap ? sw : sh;
+    static const double one[13] = {1};
+    rc = fused_checks(fn, ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, one, n_frames, n_frames, GF_BORDER_CONSTANT);
+    if (rc) return rc;
+    DeviceGuard dg(((Ctx*)ctx)->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", fn);
+    dim3 grid((dw + 63)/64, (dh + 3)/4, n_frames);
+    if (depth == GF_DEPTH_U8) hipLaunchKernelGGL(k_rotate_c3<uint8_t>, grid, dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)src, (unsigned)sstep, sframe, (uint8_t*)dst, dw, dh, dstep, dframe, m);
+    else                      hipLaunchKernelGGL(k_rotate_c3<uint16_t>, grid, dim3(BLOCK), 0, (hipStream_t)stream, (const uint8_t*)src, (unsigned)sstep, sframe, (uint8_t*)dst, dw, dh, dstep, dframe, m);
+    HIP_TRY(hipGetLastError());
+    return GF_OK;
+}
+
+GF_API int gf_undistort_rotate_rot_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,
+                                      void* dst, int dw, int dh, size_t dstep, size_t dframe,
+                                      const double D[4], const gf_frame_xform* xf_dev, int n_frames, int rotate_code,
+                                      int border, const double bv[4], gf_stream_t stream)
+{
+    const char* fn = "gf_undistort_rotate_rot_c3";
+    RotMap m;
+    int rc = rot_map_from_code(fn, rotate_code, sw, sh, &m); if (rc) return rc;
+    rc = fused_checks(fn, ctx, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, xf_dev, n_frames, n_frames, border);
+    if (rc) return rc;
+    Ctx* c = (Ctx*)ctx;
+    DeviceGuard dg(c->device);
+    if (!dg.ok) return fail(GF_ERR_HIP, "%s: cannot select the context's device", fn);
+    const double* lens; LensK lk;
+    LensLease lease(c, (hipStream_t)stream);
+    if (c->k1_mode != GF_KERNEL_RP) return fail(GF_ERR_UNSUPPORTED, "%s: the rotated-source form runs on the RP kernel only (rotate with gf_rotate_c3 first)", fn);
+    rc = lease.acquire(D, &lens, &lk); if (rc) return rc;
+    const FusedEnv env{c->k1_mode, c->n_cu, c->rp_tab};
+    return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, lens, lk, xf_dev, n_frames,
+                        border, bv, (hipStream_t)stream, nullptr, &m);
 }
 
 GF_API int gf_undistort_rotate_stretched_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t sframe,

@@ -5,6 +5,7 @@ Mirrors (names, argument meaning, return/ownership rules):
   cv2.convertMaps                       /root/reference/calibrate_video.py:378
   cv2.remap                             /root/reference/stabilizer.py:1442, nonlinear_stretch.py:130, gyroflow.py:275,283
   cv2.fisheye.undistortPoints           /root/reference/adaptive_zoom.py:220
+  cv2.rotate                            /root/reference/stabilizer.py:1353,1386
 
 Arrays may be torch CUDA tensors (stay on the device, work is enqueued on torch's current stream) or numpy
 arrays (uploaded, processed on cuda:<current>, downloaded: numpy in -> numpy out, like cv2).  There is no CPU
@@ -21,6 +22,7 @@ CV_32FC1 = 5
 CV_16SC2 = 11
 INTER_NEAREST, INTER_LINEAR, INTER_CUBIC = 0, 1, 2
 BORDER_CONSTANT, BORDER_REPLICATE, BORDER_TRANSPARENT = 0, 1, 5
+ROTATE_90_CLOCKWISE, ROTATE_180, ROTATE_90_COUNTERCLOCKWISE = 0, 1, 2
 
 _vp = C.c_void_p
 
@@ -196,18 +198,74 @@ def _frames4(t, what):
     return t
 
 
-def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0, map_scale=None):
+def rotate(src, rotateCode, dst=None):
+    """cv2.rotate(src, rotateCode) (stabilizer.py:1353,1386) for one frame [H,W,3] or a batch [N,H,W,3]; CUDA tensors stay on
+    the device, numpy in -> numpy out."""
+    if rotateCode not in (ROTATE_90_CLOCKWISE, ROTATE_180, ROTATE_90_COUNTERCLOCKWISE):
+        raise ValueError("rotateCode must be ROTATE_90_CLOCKWISE, ROTATE_180 or ROTATE_90_COUNTERCLOCKWISE")
+    dev = _device(src.device if isinstance(src, torch.Tensor) and src.is_cuda else None)
+    t, was_np = _to_dev(src, dev)
+    s = _frames4(t, "src")
+    n, sh, sw = s.shape[0], s.shape[1], s.shape[2]
+    dw, dh = (sw, sh) if rotateCode == ROTATE_180 else (sh, sw)
+    if dst is None or was_np:
+        d = torch.empty((n, dh, dw, 3), dtype=s.dtype, device=dev)
+    else:
+        d = _frames4(dst, "dst")
+        if tuple(d.shape) != (n, dh, dw, 3) or d.dtype != s.dtype or d.device != dev:
+            raise ValueError("dst has the wrong shape/dtype/device")
+    esz = s.element_size()
+    lib, ctx = _lib.load(), _lib.ctx(dev.index)
+    with torch.cuda.device(dev):
+        _lib.check(lib.gf_rotate_c3(ctx, _depth(s), _ptr(s), sw, sh, s.stride(1) * esz, s.stride(0) * esz, _ptr(d), d.stride(1) * esz,
+                                    d.stride(0) * esz, n, int(rotateCode), _stream(dev)))
+    out = d if t.dim() == 4 else d[0]
+    return out.cpu().numpy() if was_np else out
+
+
+def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0, map_scale=None, rotate=-1):
     """Fused get_maps + remap(INTER_LINEAR) for a batch of frames (stabilizer.py:1423-1443 per frame).
 
     src: CUDA uint8/uint16 [N,H,W,3] (or [H,W,3]; a stride-0 expand() over N reuses one input frame).
     D: the lens's distortion coefficients k1..k4 (host).  xforms_dev: CUDA float64 [N,13] from xforms_to_device().
     map_scale = (sx_num, sx_den, sy_num, sy_den): the float32 map rescale of a stretched preset (calibrate_video.py:375-380;
-    FisheyeCalibrator.map_scale()), None for ordinary presets.  Returns dst [N,out_h,out_w,3]."""
+    FisheyeCalibrator.map_scale()), None for ordinary presets.
+    rotate: a cv2.rotate code the reference would apply to every frame first (stabilizer.py:1385-1386), -1 for none; the
+    rotation is folded into the kernel's tap addressing (RP kernel), or done by rotate() where that form does not exist.
+    Returns dst [N,out_h,out_w,3]."""
     if not (isinstance(src, torch.Tensor) and src.is_cuda):
         raise TypeError("undistort_rotate works on CUDA tensors")
     dev = src.device
     s = _frames4(src, "src")
     n = s.shape[0]
+    if rotate is not None and rotate != -1:
+        if s.stride(0) == 0 and n > 1:
+            s = s[:1].contiguous().expand(n, -1, -1, -1)
+        rc = _lib.GF_ERR_UNSUPPORTED
+        if map_scale is None:
+            dw, dh = int(out_size[0]), int(out_size[1])
+            d = dst
+            if d is None:
+                d = torch.zeros((n, dh, dw, 3), dtype=s.dtype, device=dev) if borderMode == BORDER_TRANSPARENT else \
+                    torch.empty((n, dh, dw, 3), dtype=s.dtype, device=dev)
+            d4 = _frames4(d, "dst")
+            if tuple(d4.shape) != (n, dh, dw, 3) or d4.dtype != s.dtype or d4.device != dev:
+                raise ValueError("dst has the wrong shape/dtype/device")
+            if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
+                raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,13] tensor with N = number of frames")
+            esz = s.element_size()
+            lib, ctx = _lib.load(), _lib.ctx(dev.index)
+            with torch.cuda.device(dev):
+                rc = lib.gf_undistort_rotate_rot_c3(ctx, _depth(s), _ptr(s), s.shape[2], s.shape[1], s.stride(1) * esz, s.stride(0) * esz,
+                                                    _ptr(d4), dw, dh, d4.stride(1) * esz, d4.stride(0) * esz, _lib.distortion(D),
+                                                    _ptr(xforms_dev), n, int(rotate), int(borderMode), _lib.border_value(borderValue), _stream(dev))
+            if rc == _lib.GF_OK:
+                return d4 if (dst is None or dst.dim() == 4) else d4[0]
+            if rc != _lib.GF_ERR_UNSUPPORTED:
+                _lib.check(rc)
+        # no rotated form of this kernel (DIRECT / RL mode, stretched preset): rotate the batch, then the plain call
+        return undistort_rotate(_rotate_fn(s, rotate), D, xforms_dev, out_size, dst=dst,
+                                borderMode=borderMode, borderValue=borderValue, map_scale=map_scale)
     if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
         raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,13] tensor with N = number of frames")
     dw, dh = int(out_size[0]), int(out_size[1])
@@ -231,6 +289,10 @@ def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_C
                                                             _ptr(xforms_dev), n, float(map_scale[0]), float(map_scale[1]), float(map_scale[2]),
                                                             float(map_scale[3]), int(borderMode), _lib.border_value(borderValue), _stream(dev)))
     return d if (dst is None or dst.dim() == 4) else d[0]
+
+
+def _rotate_fn(src, code):
+    return rotate(src, code)
 
 
 def undistort_rotate_blend(src, D, xforms_dev, out_size, frames_per_group, n_blend, dst=None,

@@ -111,10 +111,13 @@ def frame_shard(n_frames, rank, world, multiple=1):
 
 # ----------------------------------------------------------------------------- the stabilizer
 class Stabilizer:
-    def __init__(self, source, calibration, stab_transform, fps, width, height, device=None):
+    def __init__(self, source, calibration, stab_transform, fps, width, height, device=None, video_rotation=-1):
         """source: frame source; calibration: FisheyeCalibrator or preset path; stab_transform: [F,4] (w,x,y,z);
-        width/height: size of the video frames (`orig_dimension` in the reference)."""
+        width/height: size of the video frames (`orig_dimension` in the reference); video_rotation: a cv2.rotate code applied
+        to every decoded frame before the remap (reference :89,153-164,1385-1386), -1 for none.  As in the reference (:164-165
+        swaps nothing), orig_dimension stays the decoded size for the 90 degree codes too."""
         self.cap = source
+        self.video_rotate_code = video_rotation
         if isinstance(calibration, FisheyeCalibrator):
             self.undistort = calibration
         else:
@@ -349,6 +352,11 @@ class Stabilizer:
         print("Done computing optimal Fov")
 
         mult, nblend = self.hyperlapse_multiplier, self.hyperlapse_num_blended_frames
+        rot = getattr(self, "video_rotate_code", -1)           # import_gyroflow_file may have set it (:1688)
+        rot = -1 if rot is None else int(rot)
+        if rot not in (-1, cv.ROTATE_90_CLOCKWISE, cv.ROTATE_180, cv.ROTATE_90_COUNTERCLOCKWISE):
+            print("video_rotate_code %r is not a cv2.rotate code" % (rot,))
+            return
         if borderMode == cv.BORDER_TRANSPARENT:
             sequential = True
         lo, hi = frame_shard(max(num_frames - 1, 0), rank, world, mult)     # the loop runs i = 1 .. num_frames-1
@@ -408,6 +416,8 @@ class Stabilizer:
                                                  update_new_K=False, quat=self.stab_transform[frame_num],
                                                  focalCenter=focalCenter[frame_num], device=self.device)
                 src = frame.to(self.device) if isinstance(frame, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frame)).to(self.device)
+                if rot != -1:
+                    src = cv.rotate(src, rot)                                  # :1385-1386
                 st["frame_out"] = cv.remap(src, m1, m2, cv.INTER_LINEAR, dst=st["frame_out"], borderMode=borderMode,
                                            borderValue=borderValue)
                 if nblend > 1:
@@ -442,8 +452,10 @@ class Stabilizer:
             def launch(din, dout, dxf):
                 if nblend == 1:
                     cv.undistort_rotate(din, self.undistort.D, dxf, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue,
-                                        map_scale=self.undistort.map_scale())
+                                        map_scale=self.undistort.map_scale(), rotate=rot)      # the rotation rides in the tap addresses
                 else:
+                    if rot != -1:
+                        din = cv.rotate(din, rot)
                     cv.undistort_rotate_blend(din, self.undistort.D, dxf, out_size, nblend, nblend, dst=dout[:n_groups],
                                               borderMode=borderMode, borderValue=borderValue)
                 return n_groups

@@ -152,6 +152,29 @@ GF_API int gf_undistort_rotate_c3(void* ctx, int depth, const void* src, int sw,
                            const double D_host[4], const gf_frame_xform* xf_dev, int n_frames,
                            int border, const double border_value_host[4], gf_stream_t stream);
 
+/* cv2.rotate codes as the reference passes them (`video_rotation`, stabilizer.py:89,153-164): -1 means "do not rotate". */
+#define GF_ROTATE_90_CLOCKWISE        0   /* cv2.ROTATE_90_CLOCKWISE        */
+#define GF_ROTATE_180                 1   /* cv2.ROTATE_180                 */
+#define GF_ROTATE_90_COUNTERCLOCKWISE 2   /* cv2.ROTATE_90_COUNTERCLOCKWISE */
+
+/* cv2.rotate(frame, rotate_code) for a batch of frames
+ *   replaces stabilizer.py:1385-1386 (`frame = cv2.rotate(frame, self.video_rotate_code)` in the render loop; also :1352-1353).
+ * src: n_frames stored frames of sw x sh; dst: sh x sw for the two 90 degree codes, sw x sh for ROTATE_180 (the caller
+ * sizes it; dstep >= a rotated row).  Pure index work: bit-exact. */
+GF_API int gf_rotate_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                 void* dst, size_t dstep, size_t dst_frame_stride, int n_frames, int rotate_code, gf_stream_t stream);
+
+/* The fused hot path on a source the reference would have rotated first:
+ *   replaces stabilizer.py:1385-1386 (cv2.rotate) + calibrate_video.py:383 + stabilizer.py:1442-1443 in one kernel.
+ * src holds the STORED frames (sw x sh, as decoded); the kernel remaps the frame cv2.rotate(frame, rotate_code) would produce
+ * (sh x sw for the 90 degree codes) without building it: the rotation is an index permutation of the four taps, folded into
+ * the tap addresses and the choice of weights.  Output is bit-identical to gf_rotate_c3 followed by gf_undistort_rotate_c3.
+ * Runs on the RP kernel (the default mode) only: GF_ERR_UNSUPPORTED in the DIRECT / RL modes -- rotate with gf_rotate_c3 then. */
+GF_API int gf_undistort_rotate_rot_c3(void* ctx, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
+                               void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,
+                               const double D_host[4], const gf_frame_xform* xf_dev, int n_frames, int rotate_code,
+                               int border, const double border_value_host[4], gf_stream_t stream);
+
 /* The fused hot path for STRETCHED presets (input_horizontal_stretch != 1): get_maps' other branch,
  *   replaces calibrate_video.py:376-380 (CV_32FC1 maps, `map1 * orig_w / calib_w`, `map2 * orig_h / calib_h` in float32,
  *   cv2.convertMaps) + stabilizer.py:1442-1443, for a batch of frames.
