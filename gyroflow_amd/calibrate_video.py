@@ -60,20 +60,31 @@ class FisheyeCalibrator:
 
     def load_calibration_data(self, cal_data, printinfo=False):
         """Take K, D and the calibration / original frame sizes from a preset dictionary (the JSON schema of
-        calibrate_video.py:483-518 as read at :520-587); returns the descriptive fields as extra_cam_info."""
+        calibrate_video.py:483-518 as read at :520-587); returns the descriptive fields as extra_cam_info.
+
+        Same order of events as the reference: the lens-model check, the optional summary and the version note (printed whether
+        or not printinfo is set, :536-538; a preset without "calibrator_version" raises KeyError there) all come before
+        anything but data_from_preset_file changes, so a preset that fails them leaves K and D as they were."""
         if not cal_data["use_opencv_fisheye"]:
             raise Exception("Preset not for OpenCV fisheye lens model")
+        self.data_from_preset_file = True
+        self._announce_preset(cal_data, printinfo)
+
         wh = lambda d: (d["w"], d["h"])
         lens = cal_data["fisheye_params"]
-        self.data_from_preset_file = True
         self.calib_dimension = wh(cal_data["calib_dimension"])
         stretched = "orig_dimension" in cal_data                         # preset format >= 0.3.0
-        self.orig_dimension = wh(cal_data["orig_dimension"]) if stretched else self.calib_dimension
-        self.input_horizontal_stretch = cal_data["input_horizontal_stretch"] if stretched else 1
+        if stretched:
+            orig = wh(cal_data["orig_dimension"])
+            self.input_horizontal_stretch = cal_data["input_horizontal_stretch"]
+            self.orig_dimension = orig
+        else:
+            self.input_horizontal_stretch = 1
+            self.orig_dimension = self.calib_dimension
+        self.num_images = self.num_images_used = cal_data["num_images"]
+        self.RMS_error = lens["RMS_error"]
         self.K = np.array(lens["camera_matrix"])
         self.D = np.array(lens["distortion_coeffs"])
-        self.RMS_error = lens["RMS_error"]
-        self.num_images = self.num_images_used = cal_data["num_images"]
 
         info = {"name": " ".join(cal_data.get("name").replace("_", " ").split())}
         for key, default in self._INFO_FIELDS:
@@ -83,15 +94,19 @@ class FisheyeCalibrator:
             raise KeyError("Error loading preset file")
         info.update(width=ow, height=oh, aspect=ow / oh, num_images=self.num_images)
         self.extra_cam_info = info
+        return info
+
+    @staticmethod
+    def _announce_preset(cal_data, printinfo):
+        """The console lines of calibrate_video.py:528-538."""
         if printinfo:
             print("Preset name: {}".format(cal_data["name"]))
             print("Note: {}".format(cal_data["note"]))
             print("Made with {} frames using calibrator version {} on date {}".format(
                 cal_data["num_images"], cal_data["calibrator_version"], cal_data["date"]))
-            if cal_data["calibrator_version"] != __version__:
-                print("Note: Versions don't match. Calibrator: {}, Preset: {}. Should be fine though.".format(
-                    __version__, cal_data["calibrator_version"]))
-        return info
+        preset_version = cal_data["calibrator_version"]
+        if preset_version != __version__:
+            print("Note: Versions don't match. Calibrator: {}, Preset: {}. Should be fine though.".format(__version__, preset_version))
 
     def get_calibration_data(self):
         """Preset dictionary in the reference's format (calibrate_video.py:483-518)."""

@@ -16,44 +16,67 @@ def _dp(a):
     return a.ctypes.data_as(_lib._dp)
 
 
+DEFAULT_ORIENTATION = (1, 0.0001, 0.0001, 0.0001)       # the reference's start quaternion when none is given (:78)
+
+
+def _monotone_prefix(t):
+    """Number of leading samples before the first timestamp that runs backwards (all of them if none does)."""
+    back = np.flatnonzero(t[:-1] > t[1:])
+    return t.shape[0] if back.size == 0 else int(back[0]) + 1
+
+
 class GyroIntegrator:
     def __init__(self, gyro_data, time_scaling=1, gyro_scaling=1, zero_out_time=True, initial_orientation=None, acc_data=None,
                  acc_scaling=1):
-        self.gyro = np.array(gyro_data, dtype=np.float64)
-        self.acc = None
-        self.acc_available = False
+        """Rows of gyro_data: t, gx, gy, gz (acc_data: t, ax, ay, az).  The log is taken in four steps, each a helper below:
+        pair it with the accelerometer log, cut it at the first timestamp that runs backwards, scale it, move t = 0 to the
+        first sample (reference :27-71)."""
         self.last_used_acc = False
-        if acc_data is not None and self.gyro.shape[0] == np.asarray(acc_data).shape[0]:
-            # the reference's constructor applies time_scaling / acc_scaling to the *gyro* columns here (:40-41); kept
-            self.acc_available = True
-            self.acc = np.array(acc_data, dtype=np.float64)
-            self.gyro[:, 0] *= time_scaling
-            self.gyro[:, 1:4] *= acc_scaling
-        time_order_check = self.gyro[:-1, 0] > self.gyro[1:, 0]
-        if np.any(time_order_check):
-            print("Truncated bad gyro data")
-            self.gyro = self.gyro[0:np.argmax(time_order_check) + 1, :]
-            if self.acc_available:
-                self.acc = self.acc[0:np.argmax(time_order_check) + 1, :]
-        self.gyro[:, 0] *= time_scaling
-        self.gyro[:, 1:4] *= gyro_scaling
+        self.gyro = np.array(gyro_data, dtype=np.float64)
+        self.acc, self.acc_available = self._pair_accelerometer(acc_data, time_scaling, acc_scaling)
+        self._truncate(_monotone_prefix(self.gyro[:, 0]))
+        self._scale(time_scaling, gyro_scaling)
         if zero_out_time:
-            self.gyro[:, 0] -= self.gyro[0, 0]
-            if self.acc_available:
-                self.acc[:, 0] -= self.acc[0, 0]
+            self._rebase_time()
         self.num_data_points = self.gyro.shape[0]
         self.gyro_sample_rate = self.num_data_points / (self.gyro[-1, 0] - self.gyro[0, 0])
-        if initial_orientation is not None:
-            self.initial_orientation = np.array(initial_orientation, dtype=np.float64)
-        else:
-            self.initial_orientation = np.array([1, 0.0001, 0.0001, 0.0001])
-        self.orientation = np.copy(self.initial_orientation)
-        self.orientation_list = None
-        self.time_list = None
-        self.already_integrated = False
+        self.initial_orientation = np.array(DEFAULT_ORIENTATION if initial_orientation is None else initial_orientation, dtype=np.float64)
+        self.orientation = self.initial_orientation.copy()
+        self.orientation_list = self.time_list = None
+        self.interp_times = self.interp_orientations = None
         self.smoothing_algo = None
-        self.interp_times = None
-        self.interp_orientations = None
+        self.already_integrated = False
+
+    def _pair_accelerometer(self, acc_data, time_scaling, acc_scaling):
+        """-> (acc copy or None, usable).  A log of another length is refused with the reference's message.  A usable one has a
+        side effect the reference has too (:40-41, pinned by tests/test_host.py::test_gyro_integrator_acc_scaling_quirk): the
+        time and accelerometer scale factors land on the GYRO columns here, before the regular scaling step applies
+        time_scaling a second time."""
+        if acc_data is None:
+            return None, False
+        acc = np.array(acc_data, dtype=np.float64)
+        if acc.shape[0] != self.gyro.shape[0]:
+            print("Gyro and acceleration data don't line up")
+            return None, False
+        self.gyro[:, 0] *= time_scaling
+        self.gyro[:, 1:4] *= acc_scaling
+        return acc, True
+
+    def _truncate(self, n_keep):
+        if n_keep < self.gyro.shape[0]:
+            print("Truncated bad gyro data")
+            self.gyro = self.gyro[:n_keep, :]
+            if self.acc_available:
+                self.acc = self.acc[:n_keep, :]
+
+    def _scale(self, time_scaling, gyro_scaling):
+        self.gyro[:, 0] *= time_scaling
+        self.gyro[:, 1:4] *= gyro_scaling
+
+    def _rebase_time(self):
+        self.gyro[:, 0] -= self.gyro[0, 0]
+        if self.acc_available:
+            self.acc[:, 0] -= self.acc[0, 0]
 
     def integrate_all(self, use_acc=False):
         if self.already_integrated and (use_acc == self.last_used_acc or not self.acc_available):

@@ -84,6 +84,36 @@ def test_preset_loader_errors(tmp_path):
     assert cal.get_stretched_size_from_dimension((3840, 2160)) == (2880, 2160)
 
 
+def test_preset_version_note_and_missing_fields(capsys):
+    """calibrate_video.py:528-538: the version note is printed whether or not printinfo is set, a preset without
+    "calibrator_version" raises KeyError, and both happen before K / D change."""
+    from gyroflow_amd import FisheyeCalibrator
+    from gyroflow_amd.calibrate_video import __version__
+    with open(preset_path("hero8_27k_43")) as f:
+        d = json.load(f)
+    other = dict(d); other["calibrator_version"] = "0.0.1-test"
+    FisheyeCalibrator().load_calibration_data(other)                       # printinfo=False
+    out = capsys.readouterr().out
+    assert out == "Note: Versions don't match. Calibrator: {}, Preset: 0.0.1-test. Should be fine though.\n".format(__version__)
+    same = dict(d); same["calibrator_version"] = __version__
+    FisheyeCalibrator().load_calibration_data(same)
+    assert capsys.readouterr().out == ""
+    FisheyeCalibrator().load_calibration_data(same, True)
+    lines = capsys.readouterr().out.splitlines()
+    assert lines[0] == "Preset name: " + d["name"] and lines[1] == "Note: " + d["note"] and lines[2].startswith("Made with %d frames" % d["num_images"])
+    for key, flag in (("calibrator_version", False), ("note", True), ("date", True)):
+        bad = dict(same); del bad[key]
+        cal = FisheyeCalibrator()
+        K0 = cal.K.copy()
+        with pytest.raises(KeyError):
+            cal.load_calibration_data(bad, flag)
+        np.testing.assert_array_equal(cal.K, K0)                           # nothing but data_from_preset_file was touched
+        assert cal.extra_cam_info is None and cal.data_from_preset_file
+    capsys.readouterr()
+    bad = dict(same); del bad["note"]
+    assert FisheyeCalibrator().load_calibration_data(bad)["note"] is None      # only read under printinfo
+
+
 def test_nonlinear_stretch_maps_equal_reference():
     """recompute_maps() == the reference's numpy arithmetic, every float32 bit (captured in stretch_maps.npz)."""
     from gyroflow_amd import NonlinearStretch
@@ -454,3 +484,34 @@ def test_threaded_staging_copy_equals_plain_copy():
         dst[...] = 0
         pipeline._host_copy(dst, padded[:, :shape[1]])
         np.testing.assert_array_equal(dst, src)
+
+
+def test_gyro_integrator_acc_scaling_quirk(capsys):
+    """The constructor's data preparation (/root/reference/gyro_integrator.py:27-71), case by case: with a usable accelerometer
+    log the reference multiplies the GYRO time column by time_scaling and the gyro rates by acc_scaling (:40-41) before the
+    regular scaling (:56-57) applies time_scaling again; a log of another length is refused with a message; the log is cut
+    after the first timestamp that runs backwards; zero_out_time rebases both logs."""
+    from gyroflow_amd import GyroIntegrator
+    t = np.array([10.0, 10.5, 11.0, 11.5, 12.0])
+    gyro = np.column_stack([t, np.arange(15.0).reshape(5, 3) + 1])
+    acc = np.column_stack([t, np.ones((5, 3))])
+    g = GyroIntegrator(gyro, time_scaling=2, gyro_scaling=3, acc_data=acc, acc_scaling=5, zero_out_time=False)
+    np.testing.assert_array_equal(g.gyro[:, 0], t * 2 * 2)                       # time_scaling twice
+    np.testing.assert_array_equal(g.gyro[:, 1:], gyro[:, 1:] * 5 * 3)            # acc_scaling lands on the gyro rates
+    np.testing.assert_array_equal(g.acc, acc)                                    # and the accelerometer log is left as it came
+    assert g.acc_available and g.gyro_sample_rate == 5 / (48.0 - 40.0)
+    g = GyroIntegrator(gyro, time_scaling=2, gyro_scaling=3, zero_out_time=True)
+    np.testing.assert_array_equal(g.gyro[:, 0], (t - 10.0) * 2)
+    np.testing.assert_array_equal(g.gyro[:, 1:], gyro[:, 1:] * 3)
+    assert g.acc is None and not g.acc_available
+    np.testing.assert_array_equal(g.initial_orientation, [1, 0.0001, 0.0001, 0.0001])
+    capsys.readouterr()
+    g = GyroIntegrator(gyro, acc_data=acc[:4])
+    assert capsys.readouterr().out == "Gyro and acceleration data don't line up\n" and not g.acc_available and g.acc is None
+    bad = gyro.copy(); bad[3, 0] = 10.2                                          # runs backwards after sample 2
+    g = GyroIntegrator(bad, acc_data=acc, zero_out_time=True)
+    assert capsys.readouterr().out == "Truncated bad gyro data\n"
+    assert g.num_data_points == 3 and g.acc.shape == (3, 4) and g.gyro[0, 0] == 0 and g.acc[0, 0] == 0 and g.gyro[2, 0] == 1.0
+    g = GyroIntegrator(gyro, initial_orientation=[0, 1, 0, 0])
+    np.testing.assert_array_equal(g.orientation, [0, 1, 0, 0])
+    assert g.orientation is not g.initial_orientation and gyro[0, 0] == 10.0     # the caller's array is not modified
