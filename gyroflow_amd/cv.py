@@ -404,10 +404,13 @@ def blend_accumulate(frame, acc, weight, reset):
     return acc
 
 
-def blend_finalize(acc, dtype):
-    """numpy-style truncating astype(uint8/uint16) of the float64 accumulator."""
+def blend_finalize(acc, dtype, out=None):
+    """numpy-style truncating astype(uint8/uint16) of the float64 accumulator (into `out` when given)."""
     dev = acc.device
-    out = torch.empty(acc.shape, dtype=dtype, device=dev)
+    if out is None:
+        out = torch.empty(acc.shape, dtype=dtype, device=dev)
+    elif out.dtype != dtype or out.numel() != acc.numel() or not out.is_contiguous() or out.device != dev:
+        raise ValueError("out must be a contiguous tensor of acc's size and the requested dtype")
     lib, ctx = _lib.load(), _lib.ctx(dev.index)
     with torch.cuda.device(dev):
         _lib.check(lib.gf_blend_finalize(ctx, _depth(out), _ptr(acc), _ptr(out), acc.numel(), _stream(dev)))

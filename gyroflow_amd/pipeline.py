@@ -202,3 +202,14 @@ class BatchPipeline:
     def flush(self):
         for j in range(self.depth):
             self._retire(self.slots[(self.k + j) % self.depth])
+
+    def abort(self):
+        """Forget everything in flight: wait for the three streams (uploads into a slot that was never committed included),
+        then mark every slot free without delivering its batch.  For a render that stops early; the ring stays usable."""
+        with torch.cuda.device(self.dev):
+            for st in (self.s_h2d, self.s_comp, self.s_d2h):
+                st.synchronize()
+        for slot in self.slots:
+            slot["busy"] = False
+            slot["pending"] = 0
+            slot.pop("trow", None)

@@ -322,11 +322,13 @@ class Stabilizer:
         with cv2 and is not available: the call prints that and returns, like the reference's own early exits.  Nothing
         raises out of the loop: a failed write prints and stops the render (:1486-1491).
 
-        Keyword-only extensions: `sequential=True` (always used for bg_color="HISTORY") issues the reference's per-frame
-        sequence get_maps -> remap -> blend; otherwise frames are batched (`batch` per launch, default by frame size)
-        through the pinned multi-stream pipeline and the fused kernels.  With world > 1 this rank renders only its
-        contiguous shard of the loop iterations (frame_shard); concatenating the ranks' outputs in rank order gives the
-        single-GPU result."""
+        Keyword-only extensions: `sequential=True` issues the reference's per-frame sequence get_maps -> remap -> blend with a
+        blocking download per frame; otherwise frames are batched (`batch` per launch, default by frame size and clip length)
+        through the pinned multi-stream pipeline and the fused kernels.  bg_color="HISTORY" (BORDER_TRANSPARENT: every frame
+        is drawn over the previous output, :1240-1241,1442) is batched too: the frames of a batch are chained on the GPU --
+        one fused launch per frame into the running output frame, on one stream -- so only the transfers are pipelined.
+        With world > 1 this rank renders only its contiguous shard of the loop iterations (frame_shard); concatenating the
+        ranks' outputs in rank order gives the single-GPU result (render_sharded() does that for a whole node)."""
         if isinstance(outpath, str) and outpath.split(".")[-1].lower() not in self.VALID_EXTENSIONS:
             print(f"{outpath} does not have a valid file extension")
             return
@@ -357,10 +359,9 @@ class Stabilizer:
         if rot not in (-1, cv.ROTATE_90_CLOCKWISE, cv.ROTATE_180, cv.ROTATE_90_COUNTERCLOCKWISE):
             print("video_rotate_code %r is not a cv2.rotate code" % (rot,))
             return
-        if borderMode == cv.BORDER_TRANSPARENT:
-            sequential = True
+        hist = borderMode == cv.BORDER_TRANSPARENT and not sequential       # HISTORY: frames chained on the GPU inside a batch
         lo, hi = frame_shard(max(num_frames - 1, 0), rank, world, mult)     # the loop runs i = 1 .. num_frames-1
-        stretched = self.undistort.image_is_stretched() and nblend > 1      # the fused blend kernel has no stretched-preset form
+        stretched = self.undistort.image_is_stretched() and nblend > 1 and not hist     # the fused blend kernel has no stretched-preset form
 
         old_map_enable_setting = False
         if viewer_thread is not None and display_preview:
@@ -404,7 +405,8 @@ class Stabilizer:
         def seq_state():
             nonlocal seq
             if seq is None:
-                seq = dict(frame_out=None, frame_temp=torch.zeros((out_size[1], out_size[0], 3), dtype=torch.float64, device=self.device))
+                seq = dict(frame_out=None, frame_temp=torch.zeros((out_size[1], out_size[0], 3), dtype=torch.float64, device=self.device)
+                           if nblend > 1 else None)
             return seq
 
         def seq_frame(frame, frame_num, phase, do_remap, do_emit):
@@ -430,7 +432,7 @@ class Stabilizer:
                 emit([st["frame_out"].cpu().numpy()])
 
         # ---- batched path state
-        cur = dict(slot=None, n=0, fnums=[])    # the batch being staged
+        cur = dict(slot=None, n=0, fnums=[], meta=[])    # the batch being staged (meta: (phase, emit) per frame, HISTORY only)
         group = []                              # (frame, frame_num, phase, do_emit) of the hyperlapse group being collected
         group_id = None
         prev_clean = None                       # frames of the last group that went through the fused blend kernel
@@ -445,11 +447,33 @@ class Stabilizer:
             n = cur["n"]
             if n == 0:
                 return
-            slot, fnums = cur["slot"], cur["fnums"]
-            cur.update(slot=None, n=0, fnums=[])
+            slot, fnums, meta = cur["slot"], cur["fnums"], cur["meta"]
+            cur.update(slot=None, n=0, fnums=[], meta=[])
             n_groups = n // nblend
 
+            def launch_history(din, dout, dxf):
+                """The loop body of :1431-1468 for every frame of the batch, in order, on the compute stream: frame n is remapped
+                OVER the running output frame (the pixels its source does not cover keep what frame n - 1 left there), blended
+                if a hyperlapse is on, and copied to the batch's output when the reference would write it."""
+                st = seq_state()
+                if st["frame_out"] is None:         # cv2.remap creates dst on the first call; zero-filled here and in cv.remap
+                    st["frame_out"] = torch.zeros((out_size[1], out_size[0], 3), dtype=din.dtype, device=self.device)
+                k = 0
+                for i, (phase, do_emit) in enumerate(meta):
+                    cv.undistort_rotate(din[i:i + 1], self.undistort.D, dxf[i:i + 1], out_size, dst=st["frame_out"][None],
+                                        borderMode=borderMode, borderValue=borderValue, map_scale=self.undistort.map_scale(), rotate=rot)
+                    if nblend > 1:
+                        cv.blend_accumulate(st["frame_out"], st["frame_temp"], 1 / nblend, phase == 0)
+                    if do_emit:
+                        if nblend > 1:
+                            cv.blend_finalize(st["frame_temp"], dtype, out=st["frame_out"])
+                        dout[k].copy_(st["frame_out"])
+                        k += 1
+                return k
+
             def launch(din, dout, dxf):
+                if hist:
+                    return launch_history(din, dout, dxf)
                 if nblend == 1:
                     cv.undistort_rotate(din, self.undistort.D, dxf, out_size, dst=dout[:n], borderMode=borderMode, borderValue=borderValue,
                                         map_scale=self.undistort.map_scale(), rotate=rot)      # the rotation rides in the tap addresses
@@ -461,26 +485,38 @@ class Stabilizer:
                 return n_groups
             pipe.commit(slot, n, launch, xforms(fnums))
 
-        def stage(frame, frame_num):
+        def stage(frame, frame_num, meta=None):
             nonlocal pipe
             if pipe is None:
-                b = batch if batch else self.default_batch(frame.nbytes if hasattr(frame, "nbytes") else frame.numel() * frame.element_size())
-                out_batch = b if nblend == 1 else max(1, b // nblend)
-                # the pinned ring is expensive to allocate (page-locking gigabytes): keep it between renders of the same shape
-                key = (frame.shape[0], frame.shape[1], out_size[1], out_size[0], dtype, out_batch * nblend, pipeline_depth, out_batch)
-                if getattr(self, "_pipe_key", None) == key:
-                    pipe = self._pipe
+                fbytes = frame.nbytes if hasattr(frame, "nbytes") else frame.numel() * frame.element_size()
+                if batch:
+                    b = int(batch)
+                else:       # no more ring than the clip can fill: a 30-frame render must not page-lock a 64-frame ring three times
+                    remapped = -(-(hi - lo) // mult) * nblend
+                    b = max(nblend, min(self.default_batch(fbytes), -(-remapped // max(int(pipeline_depth), 1))))
+                out_batch = b if (nblend == 1 or hist) else max(1, b // nblend)
+                in_batch = b if hist else out_batch * nblend
+                # the pinned ring is expensive to allocate (page-locking gigabytes): keep it between renders of the same shape.  A
+                # ring sized by default may be larger than this render needs; an explicit `batch` is taken literally.
+                shape_key = (frame.shape[0], frame.shape[1], out_size[1], out_size[0], dtype, pipeline_depth, nblend, hist)
+                cached, ckey = getattr(self, "_pipe", None), getattr(self, "_pipe_key", None)
+                if cached is not None and ckey is not None and ckey[0] == shape_key and \
+                        ((batch and (cached.batch, cached.out_batch) == (in_batch, out_batch)) or
+                         (not batch and ckey[1] and cached.batch >= in_batch)):
+                    pipe = cached
                     pipe.deliver = emit
                 else:
                     self._pipe = self._pipe_key = None
                     pipe = BatchPipeline(self.device, (frame.shape[0], frame.shape[1]), (out_size[1], out_size[0]), dtype,
-                                         out_batch * nblend, emit, depth=pipeline_depth, out_batch=out_batch)
-                    self._pipe, self._pipe_key = pipe, key
+                                         in_batch, emit, depth=pipeline_depth, out_batch=out_batch)
+                    self._pipe, self._pipe_key = pipe, (shape_key, not batch)
             if cur["slot"] is None:
                 cur["slot"] = pipe.acquire()
             pipe.stage(cur["slot"], cur["n"], frame)
             cur["n"] += 1
             cur["fnums"].append(frame_num)
+            if meta is not None:
+                cur["meta"].append(meta)
             if cur["n"] >= pipe.batch:
                 flush_batch()
 
@@ -507,6 +543,7 @@ class Stabilizer:
                 seq_frame(frame, frame_num, phase, True, do_emit)
             prev_clean, seq_valid = None, True
 
+        finished = False
         try:
             for frame_num, frame, phase, do_remap, do_emit, k in self.schedule(tstart + lo, hi - lo, first_iter=lo, with_iter=True):
                 if state["abort"]:
@@ -515,6 +552,10 @@ class Stabilizer:
                     dtype = torch.uint8 if str(frame.dtype).endswith("uint8") else torch.uint16
                 if sequential or stretched:
                     seq_frame(frame, frame_num, phase, do_remap, do_emit)
+                    continue
+                if hist:
+                    if do_remap:
+                        stage(frame, frame_num, (phase, do_emit))
                     continue
                 if nblend == 1:
                     if do_remap:
@@ -526,7 +567,7 @@ class Stabilizer:
                 if do_remap:
                     group.append((frame, frame_num, phase, do_emit))
             if not state["abort"]:
-                if nblend > 1 and not (sequential or stretched):
+                if nblend > 1 and not (sequential or stretched or hist):
                     # an unfinished trailing group emits nothing (as in the reference): only a group whose last blended frame
                     # was read is closed
                     if group and group[-1][3]:
@@ -534,13 +575,27 @@ class Stabilizer:
                 flush_batch()
                 if pipe is not None:
                     pipe.flush()
+                finished = True
         except KeyboardInterrupt:
             print("terminating render")
+        finally:
+            # A render that stops early (failed write, Ctrl-C, an exception from the source) leaves batches in flight in the
+            # cached ring: retire them without delivering, or the next render on this Stabilizer would write them into its sink.
+            if pipe is not None and not finished:
+                pipe.abort()
         print("Render finished")
         sink.close()
         if viewer_thread is not None:
             viewer_thread.map_function_enable = old_map_enable_setting
         return state["written"]
+
+
+    def release_pipeline(self):
+        """Drop the pinned ring renderfile keeps between renders of the same shape (several GB of page-locked host memory and as
+        much HBM for 4K batches); the next render allocates a new one."""
+        self._pipe = self._pipe_key = None
+
+    close = release_pipeline
 
 
 class OnlyUndistort:

@@ -68,8 +68,15 @@ def _quats(n, seed=0):
     dict(bg="REPLICATE", mult=3, nblend=1),
     dict(bg="REPLICATE", mult=4, nblend=2, batch=6),
     dict(bg="#102030", mult=4, nblend=4, dtype=np.uint16),
+    # bg_color="HISTORY" (BORDER_TRANSPARENT over the previous output, :1240-1241,1442): batched, the frames of a batch chained
+    # on the GPU; batch boundaries inside and between hyperlapse groups, failed reads, 16-bit frames; and the per-frame form
     dict(bg="HISTORY", mult=1, nblend=1),
     dict(bg="HISTORY", mult=3, nblend=2),
+    dict(bg="HISTORY", mult=1, nblend=1, batch=4, depth=3),
+    dict(bg="HISTORY", mult=4, nblend=3, fail_at=(6, 11, 16, 17), batch=5),
+    dict(bg="HISTORY", mult=2, nblend=2, dtype=np.uint16, batch=3),
+    dict(bg="HISTORY", mult=2, nblend=1, pinned=True, batch=7),
+    dict(bg="HISTORY", mult=3, nblend=2, sequential=True),
     dict(bg="#000000", mult=1, nblend=1, fail_at=(4, 9, 10)),
     dict(bg="#000000", mult=2, nblend=2, sequential=True, fail_at=(5,)),
     dict(bg="#000000", mult=1, nblend=1, short_stab=True),
@@ -328,3 +335,67 @@ def test_renderfile_stretched_preset_batched_equals_sequential(gpu):
         outs.append(sink.frames)
     for a, b in zip(*outs):
         np.testing.assert_array_equal(a, b)
+
+
+def test_aborted_render_does_not_leak_into_the_next(gpu):
+    """A sink that fails on its k-th write stops the render (:1486-1491) with batches still in flight in the cached ring; the
+    next render on the same Stabilizer must start clean -- same frames as a fresh Stabilizer, not the stale ones first."""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, ListSink, synthetic_frames
+    w, h, n = 338, 254, 40
+    frames = synthetic_frames(w, h, n=n, seed=3)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    stab = _quats(n + 2, seed=9)
+    kw = dict(out_size=(240, 136), smoothingFocus=-2, batch=4, pipeline_depth=3)
+
+    class FailingSink(ListSink):
+        def write(self, frame):
+            if len(self.frames) == 5:
+                raise IOError("disk full")
+            super().write(frame)
+
+    class InterruptingSource(ArraySource):
+        def read(self):
+            if self.pos == 17:
+                raise KeyboardInterrupt
+            return super().read()
+
+    st = Stabilizer(ArraySource(frames), cal, stab, 10.0, w, h, device=gpu)
+    bad = FailingSink()
+    assert st.renderfile(0.0, 3.5, bad, **kw) == 5 and len(bad.frames) == 5
+    ring = st._pipe
+    again = ListSink()
+    n2 = st.renderfile(1.0, 3.0, again, **kw)                  # another part of the clip, same ring
+    assert st._pipe is ring
+    fresh = ListSink()
+    assert Stabilizer(ArraySource(frames), cal, stab, 10.0, w, h, device=gpu).renderfile(1.0, 3.0, fresh, **kw) == n2 == len(again.frames) > 0
+    for a, b in zip(again.frames, fresh.frames):
+        np.testing.assert_array_equal(a, b)
+    # Ctrl-C out of the source: "terminating render" (:1520-1522), and again nothing stale afterwards
+    st2 = Stabilizer(InterruptingSource(frames), cal, stab, 10.0, w, h, device=gpu)
+    part = ListSink()
+    st2.renderfile(0.0, 3.5, part, **kw)
+    assert 0 < len(part.frames) < 17
+    st2.cap = ArraySource(frames)
+    again2 = ListSink()
+    assert st2.renderfile(1.0, 3.0, again2, **kw) == n2
+    for a, b in zip(again2.frames, fresh.frames):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_default_ring_is_sized_by_the_clip_and_can_be_released(gpu):
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, ArraySource, NullSink, synthetic_frames
+    w, h = 338, 254
+    frames = synthetic_frames(w, h, n=8)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    st = Stabilizer(ArraySource(frames, count=100, ring=True), cal, _quats(120, seed=1), 10.0, w, h, device=gpu)
+    assert st.default_batch(w * h * 3) == 256
+    assert st.renderfile(0.0, 3.1, NullSink(), out_size=(240, 136), smoothingFocus=-2) == 30
+    assert st._pipe.batch == 10 and st._pipe.depth == 3          # 30 frames over three slots, not 3 x 256
+    small = st._pipe
+    assert st.renderfile(0.0, 1.6, NullSink(), out_size=(240, 136), smoothingFocus=-2) == 15 and st._pipe is small     # a ring that is large enough is kept
+    assert st.renderfile(0.0, 9.1, NullSink(), out_size=(240, 136), smoothingFocus=-2) == 90 and st._pipe.batch == 30
+    st.release_pipeline()
+    assert st._pipe is None
+    assert st.renderfile(0.0, 1.6, NullSink(), out_size=(240, 136), smoothingFocus=-2) == 15 and st._pipe.batch == 5
