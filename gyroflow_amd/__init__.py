@@ -10,9 +10,10 @@ from .calibrate_video import FisheyeCalibrator           # noqa: F401
 from .nonlinear_stretch import NonlinearStretch          # noqa: F401
 from .stabilizer import Stabilizer, OnlyUndistort, ArraySource, ListSink, NullSink, synthetic_frames   # noqa: F401
 from .frameio import RawVideoSource, RawVideoSink, PinnedRingSource         # noqa: F401
+from .sharded import render_sharded, shard_layout        # noqa: F401  (also attaches Stabilizer.render_sharded)
 from .gyro_integrator import GyroIntegrator              # noqa: F401
 from .smoothing_algos import PlainSlerp                  # noqa: F401
 
 __all__ = ["cv", "FisheyeCalibrator", "AdaptiveZoom", "NonlinearStretch", "Stabilizer", "OnlyUndistort", "ArraySource", "ListSink", "NullSink",
-           "RawVideoSource", "RawVideoSink", "PinnedRingSource", "GyroIntegrator", "PlainSlerp",
+           "RawVideoSource", "RawVideoSink", "PinnedRingSource", "render_sharded", "shard_layout", "GyroIntegrator", "PlainSlerp",
            "synthetic_frames"]

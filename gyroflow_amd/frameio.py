@@ -10,15 +10,30 @@ class RawVideoSource:
     """Headerless BGR frames (uint8 bgr24 or uint16 bgr48le) in a file: read()/get_pos()/set_pos() like cv2.VideoCapture."""
 
     def __init__(self, path, width, height, dtype=np.uint8):
+        self.path = path
         self.width, self.height = int(width), int(height)
         self.dtype = np.dtype(dtype)
         self.frame_bytes = self.width * self.height * 3 * self.dtype.itemsize
+        self._open()
+
+    def _open(self):
+        path = self.path
         self._mm = np.memmap(path, dtype=self.dtype, mode="r")
         self.count = self._mm.size // (self.width * self.height * 3)
         if self.count == 0:
             raise ValueError("%s holds no complete %dx%d frame" % (path, self.width, self.height))
         self._frames = self._mm[:self.count * self.width * self.height * 3].reshape(self.count, self.height, self.width, 3)
         self.pos = 0
+
+    # pickled as (path, geometry, position): a worker process maps the file itself (render_sharded)
+    def __getstate__(self):
+        return dict(path=self.path, width=self.width, height=self.height, dtype=self.dtype.str, pos=self.pos)
+
+    def __setstate__(self, st):
+        self.path, self.width, self.height, self.dtype = st["path"], st["width"], st["height"], np.dtype(st["dtype"])
+        self.frame_bytes = self.width * self.height * 3 * self.dtype.itemsize
+        self._open()
+        self.pos = st["pos"]
 
     def get_pos(self):
         return self.pos

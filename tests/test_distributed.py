@@ -79,3 +79,32 @@ def test_schedule_matches_reference_indexing():
     assert [e[0] for e in _schedule(st, 0.0, 4.0, 0, 1)][-1] == 9        # sixth consecutive failure stops the render
     st = _mk_stab(1, 1)
     assert [e[0] for e in _schedule(st, 3.0, 4.7, 0, 1)][-1] == 42       # stab_transform has 43 entries
+
+
+def test_shard_layout_matches_the_schedule():
+    """render_sharded's file layout: every rank's first output frame and frame count, from arithmetic alone, equal what the
+    ranks' schedules emit -- for plain renders, frame skipping and hyperlapse blends, 1 to 8 ranks."""
+    from gyroflow_amd import shard_layout
+    for mult, nblend in [(1, 1), (4, 2), (3, 3), (5, 1), (2, 7)]:
+        for world in (1, 2, 3, 4, 8):
+            st = _mk_stab(mult, nblend, n=200)
+            lay = shard_layout(0.3, 17.9, st.fps, world, mult, nblend)
+            first = 0
+            for rank, (lo, hi, f0, n_out) in enumerate(lay):
+                emits = [e for e in _schedule(st, 0.3, 17.9, rank, world) if e[4]]
+                assert (f0, n_out) == (first, len(emits)), (mult, nblend, world, rank)
+                first += n_out
+            single = [e for e in _schedule(_mk_stab(mult, nblend, n=200), 0.3, 17.9, 0, 1) if e[4]]
+            assert first == len(single)
+
+
+def test_raw_video_source_survives_pickling(tmp_path):
+    import pickle
+    from gyroflow_amd import RawVideoSource
+    p = str(tmp_path / "clip.raw")
+    np.arange(5 * 4 * 6 * 3, dtype=np.uint8).tofile(p)
+    s = RawVideoSource(p, 6, 4)
+    s.set_pos(3)
+    t = pickle.loads(pickle.dumps(s))
+    assert (t.count, t.get_pos()) == (5, 3)
+    np.testing.assert_array_equal(t.read()[1], s.read()[1])

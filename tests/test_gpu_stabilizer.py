@@ -399,3 +399,36 @@ def test_default_ring_is_sized_by_the_clip_and_can_be_released(gpu):
     st.release_pipeline()
     assert st._pipe is None
     assert st.renderfile(0.0, 1.6, NullSink(), out_size=(240, 136), smoothingFocus=-2) == 15 and st._pipe.batch == 5
+
+
+@pytest.mark.parametrize("mult,nblend", [(1, 1), (4, 2)])
+def test_render_sharded_writes_the_single_gpu_file(gpu, tmp_path, mult, nblend):
+    """The whole-node entry: two fresh worker processes (both on cuda:0 here: oversubscribe) render their shards into their byte
+    ranges of one raw file; the file equals the single-process render byte for byte.  A clip from a raw file (the workers map
+    it themselves) and, for the short-data case, holes closed when a worker runs out of stabilisation data."""
+    from gyroflow_amd import Stabilizer, FisheyeCalibrator, RawVideoSource, synthetic_frames, render_sharded
+    w, h, n = 338, 254, 45
+    src_path = str(tmp_path / "clip.raw")
+    np.stack(synthetic_frames(w, h, n=n, seed=21)).tofile(src_path)
+    cal = FisheyeCalibrator()
+    cal.load_calibration_json(preset_path("hero8_27k_43"))
+    stab = _quats(n + 3, seed=4)
+    kw = dict(out_size=(240, 136), fov_scale=1.1, smoothingFocus=-2, bg_color="#102030", batch=6, pipeline_depth=2)
+    one = str(tmp_path / "one.raw"); two = str(tmp_path / "two.raw")
+    st = Stabilizer(RawVideoSource(src_path, w, h), cal, stab, 10.0, w, h, device=gpu)
+    st.set_hyperlapse(mult, nblend)
+    n1 = st.renderfile(0.2, 4.3, one, **kw)
+    assert n1 > 0
+    n2 = st.render_sharded(2, 0.2, 4.3, two, oversubscribe=True, **kw)
+    assert n2 == n1
+    a, b = np.fromfile(one, np.uint8), np.fromfile(two, np.uint8)
+    assert a.size == n1 * 240 * 136 * 3 and np.array_equal(a, b)
+    # stabilisation data that ends inside the second worker's shard: the file holds the frames that exist, in order
+    short = stab[:30]
+    st2 = Stabilizer(RawVideoSource(src_path, w, h), cal, short, 10.0, w, h, device=gpu)
+    st2.set_hyperlapse(mult, nblend)
+    m1 = st2.renderfile(0.2, 4.3, one, **kw)
+    m2 = render_sharded(2, RawVideoSource(src_path, w, h), cal, short, 10.0, w, h, 0.2, 4.3, two, hyperlapse=(mult, nblend),
+                        oversubscribe=True, **kw)
+    assert 0 < m1 == m2 < n1 and np.array_equal(np.fromfile(one, np.uint8), np.fromfile(two, np.uint8))
+    assert render_sharded(2, RawVideoSource(src_path, w, h), cal, stab, 10.0, w, h, 0.2, 4.3, two, oversubscribe=True, bg_color="HISTORY") is None
