@@ -414,7 +414,7 @@ def test_render_sharded_writes_the_single_gpu_file(gpu, tmp_path, mult, nblend):
     cal.load_calibration_json(preset_path("hero8_27k_43"))
     stab = _quats(n + 3, seed=4)
     kw = dict(out_size=(240, 136), fov_scale=1.1, smoothingFocus=-2, bg_color="#102030", batch=6, pipeline_depth=2)
-    one = str(tmp_path / "one.raw"); two = str(tmp_path / "two.raw")
+    one = str(tmp_path / "one.yuv"); two = str(tmp_path / "two.yuv")
     st = Stabilizer(RawVideoSource(src_path, w, h), cal, stab, 10.0, w, h, device=gpu)
     st.set_hyperlapse(mult, nblend)
     n1 = st.renderfile(0.2, 4.3, one, **kw)
