@@ -15,8 +15,8 @@ def test_algorithmic_bytes_match_survey():
     assert bench.algorithmic_bytes_per_unit("c1") == 6220800 + 6220800
     assert bench.algorithmic_bytes_per_unit("c2") == 16451136 + 6220800
     assert bench.algorithmic_bytes_per_unit("c3") == 24883200 * 2
-    assert bench.algorithmic_bytes_per_unit("c4_twopass") == 36000000 + 2 * 18662400 + 24883200
-    assert bench.algorithmic_bytes_per_unit("c4") == 36000000 + 24883200
+    assert bench.algorithmic_bytes_per_unit("c4") == 36000000 + 2 * 18662400 + 24883200
+    assert bench.algorithmic_bytes_per_unit("c4_fused") == 36000000 + 24883200
     assert bench.algorithmic_bytes_per_unit("c5") == 4 * 95233536 + 95233536
     assert bench.algorithmic_bytes_per_unit("c5_noblend") == 2 * 95233536
 

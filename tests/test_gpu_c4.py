@@ -99,7 +99,7 @@ def test_c4_fused_equals_two_launches_small(gpu, orc, border):
     xf = cv.xforms_to_device(cal.frame_xforms(1.0, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
     mid = cv.undistort_rotate(src, cal.D, xf, (ow, oh), borderMode=border, borderValue=(7, 8, 9))
     two = ns.apply_stretch_batch(mid)
-    one = cv.undistort_rotate_superview(src, cal.D, xf, (ow, oh), ns.map1[0], ns.map2[:, 0], borderMode=border, borderValue=(7, 8, 9))
+    one = cv.undistort_rotate_superview(src, cal.D, xf, (ow, oh), ns.map1[0], ns.map2[:, 0], borderMode=border, borderValue=(7, 8, 9), fused=True)
     assert one.shape == two.shape
     bad = (one != two).any(dim=-1)
     assert not bool(bad.any()), "fused chain differs from the two launches at %s" % (torch.nonzero(bad)[:5].tolist(),)
@@ -122,10 +122,11 @@ def test_c4_fused_equals_two_launches_full_size(gpu):
     xf = cv.xforms_to_device(cal.frame_xforms(1.0, q, output_dim=(ow, oh), new_img_dim=(w, h)), gpu)
     mid = cv.undistort_rotate(frames, cal.D, xf, (ow, oh))
     two = cv.superview_cubic(mid, torch.from_numpy(mx).to(gpu), torch.from_numpy(my).to(gpu))
-    one = cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my)
+    one = cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my, fused=True)
+    assert torch.equal(one, cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my))      # the default: two launches
     assert torch.equal(one, two)
     big = torch.full((2, 2160, 3841, 3), 55, dtype=torch.uint8, device=gpu)
-    cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my, dst=big[:, :, :3840])
+    cv.undistort_rotate_superview(frames, cal.D, xf, (ow, oh), mx, my, dst=big[:, :, :3840], fused=True)
     assert torch.equal(big[:, :, :3840], two) and int((big[:, :, 3840] != 55).sum()) == 0
 
 
@@ -144,7 +145,7 @@ def test_c4_fused_other_maps_and_fallback(gpu):
         ns.set_safe_area(safe)
         ns.recompute_maps()
         two = ns.apply_stretch_batch(mid)
-        one = cv.undistort_rotate_superview(src, cal.D, xf, (ow, oh), ns.map1[0], ns.map2[:, 0])
+        one = cv.undistort_rotate_superview(src, cal.D, xf, (ow, oh), ns.map1[0], ns.map2[:, 0], fused=True)
         assert torch.equal(one, two), (out_size, safe, expo)
     # the C ABI itself refuses what the kernel cannot do
     lib, ctx = _lib.load(), _lib.ctx(gpu.index or 0)

@@ -198,7 +198,7 @@ def test_fused_superview_random_case(gpu, seed):
     border = [0, 1][seed % 2]
     mid = cv.undistort_rotate(src, D, xf, (mw, mh), borderMode=border, borderValue=(3, 60, 200))
     two = ns.apply_stretch_batch(mid)
-    one = cv.undistort_rotate_superview(src, D, xf, (mw, mh), ns.map1[0], ns.map2[:, 0], borderMode=border, borderValue=(3, 60, 200))
+    one = cv.undistort_rotate_superview(src, D, xf, (mw, mh), ns.map1[0], ns.map2[:, 0], borderMode=border, borderValue=(3, 60, 200), fused=True)
     # the border mode is the remap step's (stabilizer.py:1442); the stretch step keeps the reference's default, constant 0
     # (nonlinear_stretch.py:130) -- in the one-launch form too
     assert torch.equal(one, two), "case %d: %dx%d -> %dx%d -> %dx%d" % (seed, sw, sh, mw, mh, ow, oh)
