@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--depth", type=int, default=3)
     ap.add_argument("--source", default="pinned", choices=["pinned", "raw", "array"])
     ap.add_argument("--hyperlapse", default="1,1")
+    ap.add_argument("--bg", default="#000000", help='renderfile\'s bg_color: a colour, "REPLICATE", or "HISTORY" (frames chained on the GPU)')
+    ap.add_argument("--sequential", action="store_true", help="the per-frame form of the loop (one blocking download per frame)")
+    ap.add_argument("--rotate", type=int, default=-1, help="video_rotation: a cv2.rotate code folded into the kernel (-1 = none)")
     ap.add_argument("--overlap", action="store_true", help="HIP-event timeline of the three streams during the timed render (printed after the JSON line)")
     args = ap.parse_args()
     preset, w, h, ow, oh, dt = CONFIGS[args.config]
@@ -58,10 +61,12 @@ def main():
                 f = raw._frames[self.pos % raw.count]; self.pos += 1
                 return True, f
         src = Loop(args.frames + 8)
-    st = Stabilizer(src, cal, q, fps, w, h, device=dev)
+    st = Stabilizer(src, cal, q, fps, w, h, device=dev, video_rotation=args.rotate)
+    if args.rotate in (0, 2):
+        ow, oh = oh, ow              # remap the turned frame to a turned output
     mult, nb = (int(v) for v in args.hyperlapse.split(","))
     st.set_hyperlapse(mult, nb)
-    kw = dict(out_size=(ow, oh), smoothingFocus=-2, batch=args.batch or None, pipeline_depth=args.depth)
+    kw = dict(out_size=(ow, oh), smoothingFocus=-2, batch=args.batch or None, pipeline_depth=args.depth, bg_color=args.bg, sequential=args.sequential)
     st.renderfile(0.0, (min(args.frames, 200) + 1.5) / fps, NullSink(), **kw)          # warm-up: allocations, first-touch, lens table
     torch.cuda.synchronize()
     sink = NullSink()
@@ -77,7 +82,7 @@ def main():
                       "seconds": dt_s, "frames_per_s": n_in / dt_s, "h2d_GBps": n_in * w * h * 3 * esz / dt_s / 1e9,
                       "d2h_GBps": n * ow * oh * 3 * esz / dt_s / 1e9,
                       "batch": args.batch or Stabilizer.default_batch(w * h * 3 * esz), "depth": args.depth,
-                      "hyperlapse": [mult, nb], "checksum": sink.checksum}))
+                      "hyperlapse": [mult, nb], "bg_color": args.bg, "sequential": args.sequential, "rotate": args.rotate, "checksum": sink.checksum}))
     if args.overlap and getattr(st, "_pipe", None) is not None:
         overlap_report(st._pipe.trace_table())
 
