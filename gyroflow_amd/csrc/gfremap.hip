@@ -3251,11 +3251,19 @@ GF_API int gf_undistort_rotate_c3_noalloc(int device, int depth, const void* src
     NoAllocScratch* S = nd.ptr;
     // Every call rewrites what it uses (the array keeps the last call's contents, and a captured graph must be
     // self-contained): lens table, RP table, this call's transforms.  Stream order puts them before the fused kernel.
-    static thread_local double host_tab[LENS_DOUBLES > RP_TAB_DOUBLES ? LENS_DOUBLES : RP_TAB_DOUBLES];
-    build_lens_table(D, host_tab);
-    rc = scratch_put(S->lens, host_tab, LENS_DOUBLES, (hipStream_t)stream); if (rc) return rc;
-    build_rp_table(host_tab);
-    rc = scratch_put(S->rp, host_tab, RP_TAB_DOUBLES, (hipStream_t)stream); if (rc) return rc;
+    // The host copies of the tables are kept between calls (under g_noalloc_mu, held here): the long-double lens table costs
+    // about a millisecond to build, and a serving loop calls with the same lens every time.  The device copies are still
+    // rewritten by every call.
+    static double host_lens[LENS_DOUBLES], host_rp[RP_TAB_DOUBLES], host_lens_D[4];
+    static bool host_lens_valid = false, host_rp_valid = false;
+    if (!host_lens_valid || memcmp(host_lens_D, D, sizeof host_lens_D) != 0) {
+        build_lens_table(D, host_lens);
+        memcpy(host_lens_D, D, sizeof host_lens_D);
+        host_lens_valid = true;
+    }
+    if (!host_rp_valid) { build_rp_table(host_rp); host_rp_valid = true; }
+    rc = scratch_put(S->lens, host_lens, LENS_DOUBLES, (hipStream_t)stream); if (rc) return rc;
+    rc = scratch_put(S->rp, host_rp, RP_TAB_DOUBLES, (hipStream_t)stream); if (rc) return rc;
     rc = scratch_put(&S->xf[0][0], (const double*)xf_host, n_frames*13, (hipStream_t)stream); if (rc) return rc;
     const FusedEnv env{g_k1_mode == GF_KERNEL_DIRECT ? GF_KERNEL_DIRECT : GF_KERNEL_RP, nd.n_cu, S->rp};
     return launch_fused(&env, depth, src, sw, sh, sstep, sframe, dst, dw, dh, dstep, dframe, S->lens, lk, (const gf_frame_xform*)&S->xf[0][0], n_frames,

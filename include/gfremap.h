@@ -213,7 +213,11 @@ GF_API int gf_undistort_rotate_superview_u8c3(void* ctx, const uint8_t* src, int
  * HOST array of n_frames transforms, read before the call returns) reach the device as kernel arguments of small
  * launches queued on `stream` ahead of the fused kernel.  n_frames <= GF_NOALLOC_MAX_FRAMES, else GF_ERR_INVALID_ARG.
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (two streams, two threads) race;
- * calls queued on one stream do not.  Kernel variant: RP (DIRECT if the process runs with GF_K1=direct). */
+ * calls queued on one stream do not.  Kernel variant: RP (DIRECT if the process runs with GF_K1=direct).
+ * The first call on a device resolves the array's address (hipGetSymbolAddress, which loads the library's code object on that
+ * device -- the runtime may allocate there): make one warm-up call per device before capturing a graph.  Host cost of a call:
+ * about 14 argument-carrying launches of <= 2 KB each; the host copy of the lens table is rebuilt (about 1 ms) only when
+ * D_host differs from the previous call's.  The calls of one process are serialised by a mutex. */
 #define GF_NOALLOC_MAX_FRAMES 64
 GF_API int gf_undistort_rotate_c3_noalloc(int device, int depth, const void* src, int sw, int sh, size_t sstep, size_t src_frame_stride,
                                    void* dst, int dw, int dh, size_t dstep, size_t dst_frame_stride,

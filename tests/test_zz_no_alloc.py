@@ -61,6 +61,29 @@ def test_noalloc_equals_existing_entry_two_calls(gpu):
     assert torch.equal(a3, a) and torch.equal(b3, a)
 
 
+def test_noalloc_call_leaves_device_memory_alone(gpu):
+    """After the warm-up call on the device (which resolves the static array's address), a call changes neither the free device
+    memory the driver reports (hipMemGetInfo) nor what torch's allocator holds."""
+    from gyroflow_amd import _lib
+    lib = _lib.load()
+    cal, xf, frames = _case(gpu, "hero8_27k_43", 960, 540, 960, 540, 3, np.uint8, 6)
+    dst = torch.zeros((3, 540, 960, 3), dtype=torch.uint8, device=gpu)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    D, B = _lib.distortion(cal.D), _lib.border_value(0)
+    st = C.c_void_p(torch.cuda.current_stream(gpu).cuda_stream)
+    call = lambda: lib.gf_undistort_rotate_c3_noalloc(gpu.index or 0, 0, p(frames), 960, 540, 960 * 3, 540 * 960 * 3, p(dst), 960, 540, 960 * 3,
+                                                      540 * 960 * 3, D, xf.ctypes.data_as(C.c_void_p), 3, 0, B, st)
+    assert call() == 0                       # warm-up
+    torch.cuda.synchronize(gpu)
+    free0, _ = torch.cuda.mem_get_info(gpu)
+    held0, reserved0 = torch.cuda.memory_allocated(gpu), torch.cuda.memory_reserved(gpu)
+    for _ in range(5):
+        assert call() == 0
+    torch.cuda.synchronize(gpu)
+    free1, _ = torch.cuda.mem_get_info(gpu)
+    assert free1 == free0 and torch.cuda.memory_allocated(gpu) == held0 and torch.cuda.memory_reserved(gpu) == reserved0
+
+
 def test_noalloc_rejects_oversize_and_bad_arguments(gpu):
     from gyroflow_amd import _lib
     lib = _lib.load()

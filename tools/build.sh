@@ -11,6 +11,8 @@ for v in "$@"; do
     nogather) hipcc $F -DGF_ABL_NOGATHER -o tools/_build/lib_nogather.so gyroflow_amd/csrc/gfremap.hip ;;
     noload) hipcc $F -DGF_ABL_NOLOAD -o tools/_build/lib_noload.so gyroflow_amd/csrc/gfremap.hip ;;
     nostore) hipcc $F -DGF_ABL_NOSTORE -o tools/_build/lib_nostore.so gyroflow_amd/csrc/gfremap.hip ;;
+    nobarrier) hipcc $F -DGF_ABL_NOBARRIER -o tools/_build/lib_nobarrier.so gyroflow_amd/csrc/gfremap.hip ;;
+    noload_nostore) hipcc $F -DGF_ABL_NOLOAD -DGF_ABL_NOSTORE -o tools/_build/lib_noload_nostore.so gyroflow_amd/csrc/gfremap.hip ;;
     k1_*) # k1_<pipeline>_<waves>, e.g. k1_0_8
         IFS=_ read -r _ pl wv <<< "$v"
         hipcc $F -DGF_K1_PIPELINE=$pl -DGF_K1_WAVES=$wv -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
