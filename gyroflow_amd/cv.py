@@ -372,9 +372,9 @@ def undistort_rotate_superview(src, D, xforms_dev, mid_size, mapx_row, mapy_col,
     n = s.shape[0]
     if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
         raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,13] tensor with N = number of frames")
-    mx = np.ascontiguousarray(mapx_row.detach().cpu().numpy() if isinstance(mapx_row, torch.Tensor) else mapx_row, dtype=np.float32).reshape(-1)
-    my = np.ascontiguousarray(mapy_col.detach().cpu().numpy() if isinstance(mapy_col, torch.Tensor) else mapy_col, dtype=np.float32).reshape(-1)
-    dw, dh = mx.size, my.size
+    host = lambda m: np.ascontiguousarray(m.detach().cpu().numpy() if isinstance(m, torch.Tensor) else m, dtype=np.float32).reshape(-1)
+    ondev = lambda m: m.reshape(-1) if (isinstance(m, torch.Tensor) and m.is_cuda) else torch.from_numpy(host(m)).to(dev)
+    dw, dh = int(np.prod(mapx_row.shape)), int(np.prod(mapy_col.shape))
     mw, mh = int(mid_size[0]), int(mid_size[1])
     if dst is None:
         d = torch.empty((n, dh, dw, 3), dtype=torch.uint8, device=dev)
@@ -388,12 +388,12 @@ def undistort_rotate_superview(src, D, xforms_dev, mid_size, mapx_row, mapy_col,
             # BORDER_TRANSPARENT leaves uncovered pixels as they are: without a caller's buffer they are zeros, as in cv.remap
             m = (torch.zeros if borderMode == BORDER_TRANSPARENT else torch.empty)((n, mh, mw, 3), dtype=torch.uint8, device=dev)
         undistort_rotate(s, D, xforms_dev, (mw, mh), dst=m, borderMode=borderMode, borderValue=borderValue)
-        superview_cubic(m, torch.from_numpy(mx).to(dev) if not (isinstance(mapx_row, torch.Tensor) and mapx_row.is_cuda) else mapx_row,
-                        torch.from_numpy(my).to(dev) if not (isinstance(mapy_col, torch.Tensor) and mapy_col.is_cuda) else mapy_col, dst=d)
+        superview_cubic(m, ondev(mapx_row), ondev(mapy_col), dst=d)        # maps already on the device are used where they lie
 
     if not fused:
         two_launches()
         return d if (src.dim() == 4) else d[0]
+    mx, my = host(mapx_row), host(mapy_col)          # the fused entry takes the maps from the host (cached per context)
     lib, ctx = _lib.load(), _lib.ctx(dev.index)
     with torch.cuda.device(dev):
         rc = lib.gf_undistort_rotate_superview_u8c3(ctx, _ptr(s), s.shape[2], s.shape[1], s.stride(1), s.stride(0), mw, mh,
