@@ -1333,12 +1333,19 @@ __device__ __forceinline__ void interp_u8_raw(const uint32_t* box, unsigned ru, 
 __device__ unsigned long long g_wg_trace[8192][3];
 #endif
 
+#ifndef GF_RP_WAVES_U16
+#define GF_RP_WAVES_U16 GF_RP_WAVES
+#endif
 template <int DEPTH, int BORDER, bool ROT = false>
-__global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+__global__ void __launch_bounds__(BLOCK, DEPTH == GF_DEPTH_U16 ? GF_RP_WAVES_U16 : GF_RP_WAVES) k_undistort_rotate_rp(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
                                                                 const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work,
                                                                 typename RotT<ROT>::T rot)
 {
+#ifdef GF_RP_LENS_GLOBAL
+    const double2* s_tab = (const double2*)lens;       // experiment: the lens table read where it lies (rp_nodes and the rare per-pixel tiles only)
+#else
     __shared__ double2 s_tab[LENS_DOUBLES/2];
+#endif
     __shared__ RpShared S;
 #ifdef GF_TRACE_WG
     if (threadIdx.x == 0 && blockIdx.x < 8192) {
@@ -1348,7 +1355,9 @@ __global__ void __launch_bounds__(BLOCK, GF_RP_WAVES) k_undistort_rotate_rp(Rema
         g_wg_trace[blockIdx.x][0] = wall_clock64(); g_wg_trace[blockIdx.x][2] = ((unsigned long long)xcc << 32) | hwid;
     }
 #endif
+#ifndef GF_RP_LENS_GLOBAL
     load_lens_table(lens, s_tab);
+#endif
     constexpr bool HI16 = DEPTH == GF_DEPTH_U8;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     rp_load_consts(rp_tab, S.K, tid, BLOCK);
