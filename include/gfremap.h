@@ -78,7 +78,9 @@ GF_API int gf_ctx_set_kernel_mode(void* ctx, int mode);
  * per-context table of the radial scale function theta_d(atan r)/r for each distinct D (up to 4 lenses cached; the
  * first call with a new D builds the 16 KB table on the host, uploads it on the call's stream and waits for that
  * upload -- every later call is asynchronous; a fifth distinct D evicts the least recently used table after waiting, on
- * per-slot events, for the launches that read it).  A context may be used from several threads and streams at once. */
+ * per-slot events, for the launches that read it).  A context may be used from several threads and streams at once; the
+ * context's mutex is held from a call's cache lookup until its kernel is queued, and a miss (table build, upload, wait; an
+ * eviction's wait) happens under it, so other threads' calls on the same context queue behind a miss. */
 typedef struct gf_frame_xform {
     double iR[9];
     double f[2];
