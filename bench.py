@@ -410,7 +410,10 @@ def main():
             n_cpu = args.cpu_frames
             if n_cpu < 0:      # >= 100 timed frames after 10 warm-up frames (about 10-30 s of CPU work)
                 n_cpu = {"c1": 200, "c2": 200, "c3": 100, "c4": 100, "c4_fused": 100, "c5": 25, "c5_noblend": 100}[cfg]
-            if n_cpu > 0:
+            have_oracle = os.path.isdir(os.path.join(ROOT, "oracle"))
+            if n_cpu > 0 and not have_oracle:       # the CPU legs are the oracle's; the GPU line does not depend on them
+                out["cpu_baseline"] = {"error": "oracle/ is not present: no CPU baseline and no touched-footprint figure"}
+            if n_cpu > 0 and have_oracle:
                 threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
                 out["cpu_baseline"] = cpu_baseline(cfg, cal, quats, ring, n_cpu, threads)
                 if cfg not in STRETCH and nb == 1:

@@ -223,6 +223,9 @@ def rotate(src, rotateCode, dst=None):
     return out.cpu().numpy() if was_np else out
 
 
+_cv_rotate = rotate          # undistort_rotate() has a parameter of that name
+
+
 def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_CONSTANT, borderValue=0, map_scale=None, rotate=-1):
     """Fused get_maps + remap(INTER_LINEAR) for a batch of frames (stabilizer.py:1423-1443 per frame).
 
@@ -264,7 +267,7 @@ def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_C
             if rc != _lib.GF_ERR_UNSUPPORTED:
                 _lib.check(rc)
         # no rotated form of this kernel (DIRECT / RL mode, stretched preset): rotate the batch, then the plain call
-        return undistort_rotate(_rotate_fn(s, rotate), D, xforms_dev, out_size, dst=dst,
+        return undistort_rotate(_cv_rotate(s, rotate), D, xforms_dev, out_size, dst=dst,
                                 borderMode=borderMode, borderValue=borderValue, map_scale=map_scale)
     if xforms_dev.dtype != torch.float64 or not xforms_dev.is_cuda or xforms_dev.numel() != n * _lib.XFORM_DOUBLES or not xforms_dev.is_contiguous():
         raise ValueError("xforms_dev must be a contiguous CUDA float64 [N,13] tensor with N = number of frames")
@@ -289,10 +292,6 @@ def undistort_rotate(src, D, xforms_dev, out_size, dst=None, borderMode=BORDER_C
                                                             _ptr(xforms_dev), n, float(map_scale[0]), float(map_scale[1]), float(map_scale[2]),
                                                             float(map_scale[3]), int(borderMode), _lib.border_value(borderValue), _stream(dev)))
     return d if (dst is None or dst.dim() == 4) else d[0]
-
-
-def _rotate_fn(src, code):
-    return rotate(src, code)
 
 
 def undistort_rotate_blend(src, D, xforms_dev, out_size, frames_per_group, n_blend, dst=None,

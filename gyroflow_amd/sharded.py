@@ -9,7 +9,6 @@ offset of its first frame in the common file: worker r writes frames [first_r, f
 like the single-GPU render.  bg_color="HISTORY" makes frame n depend on output n - 1 and does not shard.
 """
 import multiprocessing
-import os
 
 import numpy as np
 
@@ -149,23 +148,36 @@ def render_sharded(n_gpus, source, calibration, stab_transform, fps, width, heig
                 p.terminate()
                 p.join()
     written = [results.get(r, (0, "no result"))[0] for r in range(n_gpus)]
+    failed = False
     for r in range(n_gpus):
         err = results.get(r, (0, "no result"))[1]
         if err:
             print("render_sharded: worker %d failed: %s" % (r, err))
-    # A worker that wrote fewer frames than its slot holds (stabilisation data ran out, reads failed) leaves a hole: close the
-    # holes so that the file holds the frames that exist, in order -- what the single loop would have written.
-    if written != [n for _, _, _, n in layout]:
-        pos = 0
-        with open(outpath, "r+b") as f:
-            for (lo, hi, first, n_out), w in zip(layout, written):
-                if w and first != pos:
-                    for j in range(w):
-                        f.seek((first + j) * frame_bytes); buf = f.read(frame_bytes)
-                        f.seek((pos + j) * frame_bytes); f.write(buf)
-                pos += w
-            f.truncate(pos * frame_bytes)
+            failed = True
+    if failed:          # how far a failed worker got is unknown: the file is left as the workers wrote it, and not vouched for
+        return
+    close_holes(outpath, layout, written, frame_bytes)
     return sum(written)
+
+
+def close_holes(outpath, layout, written, frame_bytes):
+    """A worker that wrote fewer frames than its slot holds (stabilisation data ran out, reads failed) leaves a hole in the
+    common file: move the later workers' frames down so that the file holds the frames that exist, in order -- what the
+    single loop would have written -- and cut it there.  Frames only ever move towards the start, one at a time, so the
+    copy is safe in place."""
+    if list(written) == [n for _, _, _, n in layout]:
+        return
+    pos = 0
+    with open(outpath, "r+b") as f:
+        for (lo, hi, first, n_out), w in zip(layout, written):
+            if w and first != pos:
+                for j in range(w):
+                    f.seek((first + j) * frame_bytes)
+                    buf = f.read(frame_bytes)
+                    f.seek((pos + j) * frame_bytes)
+                    f.write(buf)
+            pos += w
+        f.truncate(pos * frame_bytes)
 
 
 def _render_sharded_method(self, n_gpus, starttime, stoptime, outpath, frame_dtype=np.uint8, oversubscribe=False, **render_kw):

@@ -108,3 +108,30 @@ def test_raw_video_source_survives_pickling(tmp_path):
     t = pickle.loads(pickle.dumps(s))
     assert (t.count, t.get_pos()) == (5, 3)
     np.testing.assert_array_equal(t.read()[1], s.read()[1])
+
+
+def test_close_holes_compacts_the_common_file(tmp_path):
+    """render_sharded's clean-up when workers wrote fewer frames than their slots hold: later shards move down, in order."""
+    from gyroflow_amd.sharded import close_holes, RawVideoSlotSink
+    fb = 7
+    layout = [(0, 4, 0, 4), (4, 8, 4, 4), (8, 12, 8, 4)]
+    path = str(tmp_path / "out.yuv")
+    frame = lambda r, j: np.full(fb, 10 * r + j, np.uint8)
+    for written in ([4, 4, 4], [4, 2, 0], [2, 0, 3], [0, 4, 1], [0, 0, 0]):
+        with open(path, "wb") as f:
+            f.truncate(12 * fb)
+        for r, (lo, hi, first, n_out) in enumerate(layout):
+            sink = RawVideoSlotSink(path, first, fb, n_out)
+            for j in range(written[r]):
+                sink.write(frame(r, j))
+            sink.close()
+        close_holes(path, layout, written, fb)
+        want = np.concatenate([frame(r, j) for r in range(3) for j in range(written[r])] or [np.zeros(0, np.uint8)])
+        np.testing.assert_array_equal(np.fromfile(path, np.uint8), want)
+    sink = RawVideoSlotSink(path, 0, fb, 1)
+    sink.write(frame(0, 0))
+    import pytest
+    with pytest.raises(IOError):
+        sink.write(frame(0, 1))                      # past the slot
+    with pytest.raises(IOError):
+        RawVideoSlotSink(path, 0, fb, 4).write(np.zeros(fb + 1, np.uint8))      # not a frame of this file
