@@ -188,6 +188,40 @@ def test_fused_full_size_4k_vs_oracle(gpu, orc, golden_calls):
     assert (sh[:3] == 0).all() and (sh[:, -5:] == 0).all()
 
 
+def test_fused_full_size_white_noise_vs_oracle(gpu, orc, golden_calls):
+    """north_star asks for final pixels within 1 LSB of cv2 when the maps come from the GPU.  For this design that is a statement
+    about the frame, not a theorem: a map entry that differs from the f64 oracle's does so by one Q5 step (1/32 px), which moves a
+    u8 pixel by at most 1/32 of the contrast between neighbouring source pixels -- up to 8 LSB.  The other full-size tests use the
+    benchmark's synthetic frame (gradient + checkerboard + +-8 noise); this one uses the worst frame there is, independent uniform
+    noise over the full range (neighbours differ by 85 on average), at C3's full size, three real rotations of the trace: every
+    differing pixel must sit on a differing map entry, stay within 8 LSB, and the count is printed."""
+    from gyroflow_amd import cv, _lib
+    z, _ = golden_calls
+    K, D, P = z["c3_4k.K"], z["c3_4k.D"], z["c3_4k.P"]
+    from scipy.spatial.transform import Rotation
+    q = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "quats_gyroflow_sample.npz"))["stab_transform"][[100, 700, 1300], 3:7]
+    rng = np.random.default_rng(2024)
+    frame = rng.integers(0, 256, size=(2160, 3840, 3), dtype=np.uint8)
+    src = torch.from_numpy(frame).to(gpu)
+    tot_px = tot_map = 0
+    worst = 0
+    for qi in q:
+        R = Rotation.from_quat([qi[1], qi[2], qi[3], qi[0]]).as_matrix()
+        R[[0, 0, 1, 2], [1, 2, 0, 0]] *= -1
+        o1, o2 = orc.fisheye_init_undistort_rectify_map(K, D, R, P, (3840, 2160), orc.CV_16SC2, nthreads=8)
+        want = orc.remap_linear(frame, o1, o2, nthreads=8)
+        g1, g2 = cv.fisheye_initUndistortRectifyMap(K, D, R, P, (3840, 2160), cv.CV_16SC2, device=gpu)
+        xf = cv.xforms_to_device(_lib.xform_to_array(_lib.make_frame_xform(K, R, P))[None], gpu)
+        got = cv.undistort_rotate(src, D, xf, (3840, 2160))[0]
+        assert torch.equal(got, cv.remap(src, g1, g2, cv.INTER_LINEAR))                 # fused == maps + remap, bit for bit
+        map_diff = (g1.cpu().numpy() != o1).any(axis=-1) | (g2.cpu().numpy() != o2)
+        px_diff = np.abs(got.cpu().numpy().astype(np.int32) - want.astype(np.int32))
+        assert not (px_diff.any(axis=-1) & ~map_diff).any(), "a pixel differs where the map entries agree"
+        tot_px += int(px_diff.any(axis=-1).sum()); tot_map += int(map_diff.sum()); worst = max(worst, int(px_diff.max()))
+    print("white noise, 3 x C3: %d map entries differ from the oracle (of %d), %d pixels differ, max |diff| = %d LSB" % (tot_map, 3 * 3840 * 2160, tot_px, worst))
+    assert tot_map <= 3 * 17 and worst <= 8           # < 2e-6 of the entries, one Q5 step each
+
+
 def test_undistort_image_matches_oracle_chain(gpu, orc):
     """FisheyeCalibrator.undistort_image (calibrate_video.py:296-328): estimateNewCameraMatrixForUndistortRectify -> maps with
     R = I -> bilinear remap.  The new camera matrix goes through the GPU undistortPoints kernel (tan from the device libm):
