@@ -751,6 +751,25 @@ __device__ __forceinline__ void interp_u16_interior(const uint8_t* __restrict__ 
     bilin_u16_float(t.a, t.b, (int)(iu & 31u), (int)(iv & 31u), out);
 }
 
+#ifdef GF_RP_PREFETCH
+// One dword per lane, GF_RP_PREFETCH source rows below the lane's first tap, copied into an LDS sink nobody reads
+// (global_load_lds_dword: no destination register, nothing waits for it by name; it only has to have been served by the
+// L1 -- which then holds the line -- before the next pass's loads return, and those are behind it in the queue anyway).
+typedef __attribute__((address_space(3))) void* lds_sink_ptr;
+__device__ __forceinline__ void prefetch_rows_ahead(const SrcImg& s, unsigned iu, unsigned iv)
+{
+    __shared__ unsigned sink[BLOCK];
+    const unsigned row = min((iv >> 5) + (unsigned)(GF_RP_PREFETCH), (unsigned)s.h - 1u);
+    const unsigned off = (__umul24(row, s.step) + __umul24(iu >> 5, 3u)) & ~3u;
+    const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(lds_sink_ptr)sink + ((unsigned)threadIdx.x & ~63u)*4u));
+    const uintptr_t b = (uintptr_t)s.base;           // uniform in every caller; say so
+    const uintptr_t ub = (uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b) | ((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32)) << 32);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(ub) : "memory");
+}
+#endif
+
 template <int DEPTH> struct TapsT;
 template <> struct TapsT<GF_DEPTH_U8>  { typedef TapsU8  T; };
 template <> struct TapsT<GF_DEPTH_U16> { typedef TapsU16 T; };
@@ -773,6 +792,17 @@ __device__ __forceinline__ unsigned remap4(const SrcImg& s, const int* iu, const
     const unsigned umax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
     const unsigned vmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
     if (umax < (w1 << INTER_BITS) && vmax < (h1 << INTER_BITS)) {
+#ifdef GF_RP_PREFETCH    /* experiment (tools/exp_r03.sh): touch the rows this thread will need GF_RP_PREFETCH source rows further down, behind this pass's tap loads */
+        if constexpr (DEPTH == GF_DEPTH_U8) {
+            TapsU8 T[PXT];
+#pragma unroll
+            for (int i = 0; i < PXT; i++) T[i] = fetch_u8_interior(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i]);
+            prefetch_rows_ahead(s, (unsigned)iu[0], (unsigned)iv[0]);
+#pragma unroll
+            for (int i = 0; i < PXT; i++) bilin_u8_rows<HI16>(T[i].a, T[i].b, (unsigned)iu[i], (unsigned)iv[i], px[i]);
+            return 0;
+        }
+#endif
 #pragma unroll
         for (int i = 0; i < PXT; i++) {
             if (DEPTH == GF_DEPTH_U8) interp_u8_interior<HI16>(s.base, s.step, (unsigned)iu[i], (unsigned)iv[i], px[i]);

@@ -21,6 +21,7 @@ for v in "$@"; do
         hipcc $F -DGF_TILE_W=$tw -DGF_TILE_H=$th -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
     pairs_*) hipcc $F -DGF_COORD_PAIRS=1 -DGF_K1_WAVES=${v#pairs_} -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
     trace)    hipcc $F -DGF_TRACE_WG -o tools/_build/lib_trace.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;   # kbench --lib prints the workgroup timeline
+    pf_*)     hipcc $F -DGF_RP_PREFETCH=${v#pf_} -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;     # K1 touching its rows <n> source rows ahead
     both)     hipcc $F -DGF_ABL_NOMATH -DGF_ABL_NOGATHER -o tools/_build/lib_both.so gyroflow_amd/csrc/gfremap.hip ;;
   esac
 done
