@@ -227,13 +227,20 @@ def main():
         if os.environ.get("RANK", "0") == "0":
             print("bench.py: --gpus %d but the launcher started WORLD_SIZE %s ranks" % (args.gpus, os.environ.get("WORLD_SIZE")), file=sys.stderr)
         sys.exit(2)
+    # stdout carries the ONE JSON line and nothing else: whatever is printed on the way -- the preset loader's version note
+    # (unconditional, like the reference's), gloo's "[Gloo] Rank 0 is connected ..." from C++ -- goes to stderr, so file
+    # descriptor 1 itself is pointed there and the line is written to a copy of the original
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     rank, local_rank, world = gdist.init_from_env()      # gloo: timing barrier only; no data-path collective
     if args.dry_run:
         gdist.barrier()
         ranks = gdist.sum_over_ranks(1.0)
         top = gdist.max_over_ranks(float(rank))
         if rank == 0:
-            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_met": int(ranks), "max_rank": int(top)}), flush=True)
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_met": int(ranks), "max_rank": int(top)}), file=line_out, flush=True)
         gdist.shutdown()
         return
 
@@ -429,7 +436,7 @@ def main():
                     out["pcie_pipeline"] = pcie_pipeline(cfg, dev)
                 except Exception as e:          # an auxiliary measurement: report, do not lose the line
                     out["pcie_pipeline"] = {"error": repr(e)}
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=line_out, flush=True)
     gdist.shutdown()
 
 

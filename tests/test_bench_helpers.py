@@ -49,8 +49,8 @@ def test_gpus_n_without_launcher_spawns_n_ranks():
     import json
     r = _run_bench(["--gpus", "2", "--dry-run"])
     assert r.returncode == 0, r.stderr
-    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
-    assert lines == [{"dry_run": True, "n_gpus": 2, "ranks_met": 2, "max_rank": 1}]
+    # stdout is that one line: gloo's own "[Gloo] Rank 0 is connected ..." (written to fd 1 from C++) must not share it
+    assert [json.loads(l) for l in r.stdout.splitlines()] == [{"dry_run": True, "n_gpus": 2, "ranks_met": 2, "max_rank": 1}]
 
 
 def test_gpus_n_refuses_when_the_gpus_are_not_there():

@@ -33,6 +33,7 @@ def main():
     args = ap.parse_args()
     preset, w, h, ow, oh, dt = CONFIGS[args.config]
     dev = torch.device("cuda", 0)
+    line_out, sys.stdout = sys.stdout, sys.stderr        # stdout: the JSON line (and --overlap's table) only; the library's progress notes go to stderr
     cal = FisheyeCalibrator()
     cal.load_calibration_json(os.path.join(ROOT, "tests", "golden", "presets", preset + ".json"))
     q = np.load(os.path.join(ROOT, "tests", "golden", "quats_gyroflow_sample.npz"))["stab_transform"][:, 3:7]
@@ -78,6 +79,7 @@ def main():
     dt_s = time.perf_counter() - t0
     n_in = args.frames
     esz = np.dtype(dt).itemsize
+    sys.stdout = line_out
     print(json.dumps({"tool": "render_bench", "config": args.config, "source": args.source, "frames_in": n_in, "frames_out": n,
                       "seconds": dt_s, "frames_per_s": n_in / dt_s, "h2d_GBps": n_in * w * h * 3 * esz / dt_s / 1e9,
                       "d2h_GBps": n * ow * oh * 3 * esz / dt_s / 1e9,
