@@ -3,7 +3,7 @@
 // and times the launches with hipEvents on the launch stream.  Used for kernel A/B work; bench.py is the
 // contract benchmark.
 //
-//   kbench [--in WxH] [--out WxH] [--frames N] [--iters K] [--depth 0|2] [--border 0|1|5] [--lib path] [--blend N]
+//   kbench [--in WxH] [--out WxH] [--frames N] [--iters K] [--depth 0|2] [--border 0|1|5] [--lib path] [--blend N] [--same-src]
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <math.h>
@@ -37,7 +37,7 @@ static void rot_zyx(double z, double y, double x, double* R)
 
 int main(int argc, char** argv)
 {
-    int iw = 3840, ih = 2160, ow = 3840, oh = 2160, frames = 32, iters = 20, depth = 0, border = 0, blend = 0;
+    int iw = 3840, ih = 2160, ow = 3840, oh = 2160, frames = 32, iters = 20, depth = 0, border = 0, blend = 0, same_src = 0;
     double amp = 3.6;   // degrees, typical correction angle of the real trace
     const char* libpath = "gyroflow_amd/libgfremap.so";
     for (int i = 1; i < argc; i++) {
@@ -50,6 +50,7 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--blend") && i + 1 < argc) blend = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--amp") && i + 1 < argc) amp = atof(argv[++i]);
         else if (!strcmp(argv[i], "--lib") && i + 1 < argc) libpath = argv[++i];
+        else if (!strcmp(argv[i], "--same-src")) same_src = 1;      // every frame reads source frame 0 (frame stride 0): what the kernel costs when its source comes from L2 / the memory-side cache
         else { fprintf(stderr, "unknown arg %s\n", argv[i]); return 1; }
     }
     void* h = dlopen(libpath, RTLD_NOW);
@@ -91,9 +92,10 @@ int main(int argc, char** argv)
     if (ctx_create(0, &ctx)) { fprintf(stderr, "ctx: %s\n", last_err()); return 1; }
     hipStream_t st; CK(hipStreamCreate(&st));
     double bv[4] = {0, 0, 0, 0};
+    const size_t sfr = same_src ? 0 : sframe;
     auto launch = [&]() {
-        if (blend > 1) return fused_blend(ctx, depth, src, iw, ih, sstep, sframe, dst, ow, oh, dstep, dframe, D, xf_dev, frames/blend, blend, blend, border, bv, st);
-        return fused(ctx, depth, src, iw, ih, sstep, sframe, dst, ow, oh, dstep, dframe, D, xf_dev, frames, border, bv, st);
+        if (blend > 1) return fused_blend(ctx, depth, src, iw, ih, sstep, sfr, dst, ow, oh, dstep, dframe, D, xf_dev, frames/blend, blend, blend, border, bv, st);
+        return fused(ctx, depth, src, iw, ih, sstep, sfr, dst, ow, oh, dstep, dframe, D, xf_dev, frames, border, bv, st);
     };
     for (int i = 0; i < 3; i++) if (launch()) { fprintf(stderr, "launch: %s\n", last_err()); return 1; }
     CK(hipStreamSynchronize(st));
@@ -150,6 +152,7 @@ int main(int argc, char** argv)
             }
         }
     }
+    if (same_src) printf("[same source frame] ");
     printf("%dx%d->%dx%d depth=%d border=%d frames=%d blend=%d: median %.3f ms (min %.3f) = %.2f us/frame, %.0f frames/s, %.0f GB/s algorithmic (%.1f%% of 8 TB/s) checksum %016llx\n",
            iw, ih, ow, oh, depth, border, frames, blend, med, mn, 1e3*med/frames, frames/(med*1e-3), bytes/(med*1e-3)/1e9,
            100*bytes/(med*1e-3)/8e12, (unsigned long long)cs);
