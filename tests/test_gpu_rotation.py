@@ -69,6 +69,36 @@ def test_fused_on_rotated_source_equals_rotate_then_fused(gpu, code, border, dty
     assert torch.equal(got, want2)
 
 
+N_RANDOM = int(__import__("os").environ.get("GF_SWEEP_CASES", "36"))
+
+
+@pytest.mark.parametrize("seed", range(N_RANDOM))
+def test_rotated_fused_random_case(gpu, seed):
+    """The sweep of tests/test_gpu_sweep.py (sizes from 1 pixel up, odd pitches, lenses, rotations past 90 degrees, every border,
+    both depths) with the source stored turned: the rotated entry against numpy.rot90 + the plain entry, bit for bit."""
+    from gyroflow_amd import cv, _lib
+    from test_gpu_sweep import _case, _img
+    c = _case(seed)
+    rng, n, dtype, border = c["rng"], c["n"], c["dtype"], c["border"]
+    code = int(rng.integers(0, 3))
+    rw, rh, dw, dh = c["sw"], c["sh"], c["dw"], c["dh"]            # the frame the lens model is for: the turned one
+    turned = np.stack([_img(rng, rh, rw, dtype) for _ in range(n)])
+    stored = np.rot90(turned, k=-ROT90_K[code], axes=(-3, -2)).copy()                     # what the file holds: cv2.rotate undone
+    np.testing.assert_array_equal(np_rotate(stored, code), turned)
+    prev = np.stack([_img(rng, dh, dw, dtype) for _ in range(n)])
+    bv = (7, 200, 33) if dtype == np.uint8 else (700, 65535, 12345)
+    tdt = torch.uint8 if dtype == np.uint8 else torch.uint16
+    sth, stw = stored.shape[1:3]
+    big_s = torch.zeros((n, sth, stw + c["spad"], 3), dtype=tdt, device=gpu)               # padded, possibly odd, row pitch
+    big_s[:, :, :stw] = torch.from_numpy(stored).to(gpu)
+    xf = cv.xforms_to_device(np.stack([_lib.xform_to_array(_lib.make_frame_xform(c["K"], R, c["P"])) for R in c["Rs"]]), gpu)
+    got = cv.undistort_rotate(big_s[:, :, :stw], c["D"], xf, (dw, dh), dst=torch.from_numpy(prev.copy()).to(gpu), borderMode=border,
+                              borderValue=bv, rotate=code)
+    want = cv.undistort_rotate(torch.from_numpy(turned).to(gpu), c["D"], xf, (dw, dh), dst=torch.from_numpy(prev.copy()).to(gpu),
+                               borderMode=border, borderValue=bv)
+    assert torch.equal(got, want), "case %d, rotate code %d" % (seed, code)
+
+
 @pytest.mark.parametrize("kmode", ["direct", "rl"])
 def test_rotated_source_in_the_other_kernel_modes(gpu, kmode):
     """DIRECT / RL have no rotated form: cv.undistort_rotate(rotate=...) rotates the batch first; same bytes as that mode's plain call."""

@@ -8,6 +8,8 @@ Per case three statements, the same ones tests/test_gpu_parity.py makes for its 
   * GPU maps differ from the oracle's in at most one 1/32-px step at a vanishing fraction of entries (rounding ties);
   * where the maps agree, the fused pixels equal the oracle chain's.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -15,7 +17,12 @@ from scipy.spatial.transform import Rotation
 
 pytestmark = pytest.mark.gpu
 
-N_CASES = 36
+N_CASES = int(os.environ.get("GF_SWEEP_CASES", "36"))        # a one-off hunt can ask for thousands (seeds 0 .. N-1)
+
+
+def _n(default):
+    """seeds of the smaller sweeps: their default count, or GF_SWEEP_CASES when a hunt sets it"""
+    return range(int(os.environ.get("GF_SWEEP_CASES", default)))
 
 
 def _img(rng, h, w, dtype):
@@ -117,7 +124,7 @@ def _sv_case(seed):
                 border=[0, 1, 5][seed % 3], n=int(rng.integers(1, 4)), spad=int(rng.integers(0, 4)), dpad=int(rng.integers(0, 4)))
 
 
-@pytest.mark.parametrize("seed", range(30))
+@pytest.mark.parametrize("seed", _n(30))
 def test_superview_random_case(gpu, orc, seed):
     """gf_superview_cubic_u8c3 (separable maps, batched) == the oracle's INTER_CUBIC remap with the full 2-D maps, bit for bit:
     random sizes across the 256-column / 48-row strip boundaries, unit and other vertical steps, monotone and arbitrary
@@ -143,7 +150,7 @@ def test_superview_random_case(gpu, orc, seed):
         np.testing.assert_array_equal(got[i], want, err_msg="frame %d of case %d" % (i, seed))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", _n(12))
 def test_fused_blend_random_case(gpu, seed):
     """gf_undistort_rotate_blend_c3 == the fused remap of every input frame followed by numpy's float64 mean in the reference's
     order and its truncating cast (stabilizer.py:1434-1468): random sizes, group shapes (multiplier >= blended frames), borders."""
@@ -172,7 +179,7 @@ def test_fused_blend_random_case(gpu, seed):
     np.testing.assert_array_equal(got, np.stack(want), err_msg="case %d: n_blend %d, multiplier %d" % (seed, nb, mult))
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", _n(10))
 def test_fused_superview_random_case(gpu, seed):
     """gf_undistort_rotate_superview_u8c3 (or, outside its envelope, the fallback cv.undistort_rotate_superview takes) == the two
     launches: random source / intermediate / output sizes around the 64-pixel tile grid, random stretch settings."""
@@ -204,7 +211,7 @@ def test_fused_superview_random_case(gpu, seed):
     assert torch.equal(one, two), "case %d: %dx%d -> %dx%d -> %dx%d" % (seed, sw, sh, mw, mh, ow, oh)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", _n(8))
 def test_fused_stretched_random_case(gpu, orc, seed):
     """gf_undistort_rotate_stretched_c3 == float32 maps, numpy's float32 rescale, convertMaps, remap (calibrate_video.py:375-380
     followed by stabilizer.py:1442) on the GPU bit for bit, and the rescale + convertMaps step against the oracle."""
