@@ -1593,6 +1593,229 @@ __global__ void __launch_bounds__(BLOCK_RL, (GF_RL_WGS*(BLOCK_RL/64) + 3)/4) k_u
     }
 }
 
+#ifdef GF_LB
+// K1-LB (experiment, tools/build.sh lb): the RP kernel with its taps read from LDS.  Four waves, no producer: per HALF tile
+// (64 x 32 output pixels) the workgroup copies the source box of the next half tile into the other of two LDS buffers with
+// LDS-DMA (every wave issues its share, nothing waits for it by name) while all four waves compute the current half tile from
+// the current buffer; s_waitcnt vmcnt(0) + one barrier per half tile hand the buffers over.  The box of a half tile comes from
+// its row polynomials evaluated at the four corners (+- 2 positions); a thread whose taps are not all inside takes the
+// frame path, so results never depend on the estimate.  The lens table stays in global memory (only rp_nodes and the
+// per-pixel fallback read it): 2 x 11.5 KB of boxes + 14.7 KB of coefficients = 4 workgroups per CU.
+constexpr int LB_ROWS = 46;
+#ifdef GF_LB_STATS
+__device__ unsigned long long g_lb_stats[4];       // thread-passes from LDS, from the frame (box missed), boxes on, boxes off
+#endif
+__device__ __forceinline__ RlBox lb_box(const int (&e)[4], int sw, int sh)
+{
+    RlBox B;
+    B.bx0 = max(e[0], 2) - 2; const int bx1 = min(e[1], sw - 4) + 2;
+    B.by0 = max(e[2], 2) - 2; const int by1 = min(e[3], sh - 4) + 2;
+    B.bxB = ((unsigned)B.bx0*3u) & ~15u;
+    B.xoffB = (unsigned)B.bx0*3u - B.bxB;
+    B.nrows = by1 - B.by0 + 2;
+    const long long nbytes = (long long)(bx1 + 2)*3 - (long long)B.bxB;
+    B.on = sw >= 4 && sh >= 4 && B.bx0 <= bx1 && B.by0 <= by1 && nbytes <= RL_PITCH && B.nrows <= LB_ROWS;
+    B.NXq = B.on ? (unsigned)(bx1 - B.bx0 + 1) << INTER_BITS : 0u;
+    B.NYq = B.on ? (unsigned)(by1 - B.by0 + 1) << INTER_BITS : 0u;
+    return B;
+}
+
+// Source positions of the corners of tile rows r0 and r1 (all lanes compute; lanes 0..3 hold the corners), reduced to
+// wave-uniform min / max.
+__device__ __forceinline__ RlBox lb_box_of_rows(const double (*C)[RP_N], const RpFrameC& fc, int tx, int ty, int r0, int r1, int lane, int sw, int sh)
+{
+    const int r = (lane & 1) ? r1 : r0;
+    const int j = (lane & 2) ? RT - 1 : 0;
+    const double z = ((double)j - (RP_HALF - 0.5))*(1.0/RP_HALF);
+    const double2* c = (const double2*)C[r];
+    const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
+    double G = __fma_rn(c3.y, z, c3.x);
+    G = __fma_rn(G, z, c2.y); G = __fma_rn(G, z, c2.x); G = __fma_rn(G, z, c1.y); G = __fma_rn(G, z, c1.x);
+    G = __fma_rn(G, z, c0.y); G = __fma_rn(G, z, c0.x);
+    const RpRowC rc = rp_row_consts(fc, ty*RT + r);
+    const double dj = (double)(tx*RT + j);
+    const double X = __fma_rn(dj, rc.axp, rc.rxp), Y = __fma_rn(dj, rc.ayp, rc.ryp);
+    const double u32 = __fma_rn(X, G, rc.cx32), v32 = __fma_rn(Y, G, rc.cy32);
+    // clamp before the conversion: a wild value (a tile that is not ok) must not wrap
+    const int su = (int)fmin(fmax(u32*(1.0/32), -1e6), 1e6), sv = (int)fmin(fmax(v32*(1.0/32), -1e6), 1e6);
+    int e[4];
+    const int u0 = __builtin_amdgcn_readlane(su, 0), u1 = __builtin_amdgcn_readlane(su, 1), u2 = __builtin_amdgcn_readlane(su, 2), u3 = __builtin_amdgcn_readlane(su, 3);
+    const int v0 = __builtin_amdgcn_readlane(sv, 0), v1 = __builtin_amdgcn_readlane(sv, 1), v2 = __builtin_amdgcn_readlane(sv, 2), v3 = __builtin_amdgcn_readlane(sv, 3);
+    e[0] = min(min(u0, u1), min(u2, u3)) - 1; e[1] = max(max(u0, u1), max(u2, u3)) + 1;      // (int) truncates towards zero: one more position each way
+    e[2] = min(min(v0, v1), min(v2, v3)) - 1; e[3] = max(max(v0, v1), max(v2, v3)) + 1;
+    return lb_box(e, sw, sh);
+}
+
+// This wave's share of the copy of box B (groups of four rows: wave w takes groups w, w + 4, w + 8).
+__device__ __forceinline__ void lb_issue(const RlBox& B, const uint8_t* __restrict__ frame, unsigned sstep, unsigned limit, uint4* buf, int lane, int wave)
+{
+    if (!B.on) return;
+    const unsigned lr = (unsigned)lane >> 4, lc = (unsigned)lane & 15u;
+    const int ngroups = (B.nrows + 3) >> 2;
+    const unsigned lds0 = (unsigned)(uintptr_t)(lds_void_ptr)buf;
+#pragma unroll 1
+    for (int i = wave; i < ngroups; i += BLOCK/64) {
+        const unsigned row = (unsigned)B.by0 + min(4u*(unsigned)i + lr, (unsigned)B.nrows - 1u);
+        const unsigned off = min(row*sstep + B.bxB + lc*16u, limit);
+        const unsigned lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(lds0 + (unsigned)i*1024u));
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(off), "s"(lds_dst), "s"(frame) : "memory");
+    }
+}
+
+// Cold parts of the LB kernel as calls, so that their registers do not count against the half-tile loop.
+__device__ __noinline__ void lb_nodes_cold(const Xf* xf, const LensK* lk, const double2* tab, const double* rp_tab, int lane, int tx, int ty,
+                                           RpShared* S, int c2buf, int okslot)
+{
+    const double offx = rp_node_off(rp_tab, lane & 7), offy = rp_node_off(rp_tab, lane >> 3);
+    rp_nodes<false>(*xf, *lk, tab, offx, offy, lane & 7, lane >> 3, tx, ty, S->U, S->K, S->C2[c2buf], &S->ok[okslot], nullptr);
+}
+struct Px4 { int v[PXT][3]; unsigned keep; };
+template <int BORDER>
+__device__ __noinline__ Px4 lb_remap4_cold(const uint8_t* base, int sw, int sh, unsigned sstep, int iu0, int iu1, int iu2, int iu3, int iv0, int iv1, int iv2, int iv3,
+                                           int c0, int c1, int c2)
+{
+    const SrcImg s{base, sw, sh, sstep};
+    const int iu[PXT] = {iu0, iu1, iu2, iu3}, iv[PXT] = {iv0, iv1, iv2, iv3}, cval[3] = {c0, c1, c2};
+    Px4 r;
+    r.keep = remap4<GF_DEPTH_U8, BORDER, true>(s, iu, iv, cval, r.v);
+    return r;
+}
+
+#ifndef GF_LB_WAVES
+#define GF_LB_WAVES GF_RP_WAVES
+#endif
+template <int BORDER>
+__global__ void __launch_bounds__(BLOCK, GF_LB_WAVES) k_undistort_rotate_lb(RemapArgs A, const Xf* __restrict__ xfs, const double* __restrict__ lens, LensK lk,
+                                                                           const double* __restrict__ rp_tab, unsigned tiles_pad, unsigned n_work)
+{
+    constexpr int DEPTH = GF_DEPTH_U8;
+    constexpr bool HI16 = true;
+    static_assert(LB_ROWS*RL_PITCH % 16 == 0, "box buffers are uint4 arrays");
+    __shared__ RpShared S;
+    __shared__ uint4 s_box[2][(LB_ROWS + 2)*RL_PITCH/16];       // groups of four rows: the last group may run two rows past LB_ROWS
+    const double2* s_tab = (const double2*)lens;
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    rp_load_consts(rp_tab, S.K, tid, BLOCK);
+    const int lx = tid & (RT_TPR - 1), ly = tid / RT_TPR;
+    double z[PXT];
+#pragma unroll
+    for (int e = 0; e < PXT; e++) z[e] = ((double)(lx*PXT + e) - (RP_HALF - 0.5))*(1.0/RP_HALF);      // exact
+    const unsigned limit = ((unsigned)(A.sh - 1)*A.sstep + (unsigned)A.sw*3u - 16u) & ~15u;            // frames hold >= 32 bytes (host-checked)
+    const unsigned n_it = (n_work - blockIdx.x + gridDim.x - 1)/gridDim.x;       // work items of this workgroup (>= 1)
+    auto decode = [&](unsigned k, unsigned& frame, int& tx, int& ty) -> bool {   // uniform
+        if (k >= n_it) return false;
+        const unsigned v = blockIdx.x + k*gridDim.x;
+        frame = v / tiles_pad;
+        return tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty);
+    };
+    auto nodes = [&](unsigned k) {               // one wave
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty)) lb_nodes_cold(&xfs[frame], &lk, s_tab, rp_tab, lane, tx, ty, &S, (int)(k & 1), (int)(k & 3));
+    };
+    auto rows = [&](unsigned k) {                // all threads
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty)) rp_rows(S.C2[k & 1], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[k & 1]);
+    };
+    auto box_of = [&](unsigned k, int half) -> RlBox {      // wave-uniform; off when the item does not exist or its tile is not ok
+        RlBox B; B.on = false; B.bx0 = B.by0 = 0; B.NXq = B.NYq = 0; B.bxB = 0; B.xoffB = 0; B.nrows = 0;
+        unsigned frame; int tx, ty;
+        if (decode(k, frame, tx, ty) && S.ok[k & 3] != 0)
+            B = lb_box_of_rows(S.C[k & 1], rp_frame_consts(xfs[frame]), tx, ty, half*(RT/2), half*(RT/2) + RT/2 - 1, lane, A.sw, A.sh);
+        return B;
+    };
+    auto issue = [&](unsigned k, const RlBox& B, int buf) {
+        unsigned frame; int tx, ty;
+        if (B.on && decode(k, frame, tx, ty)) lb_issue(B, A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[buf], lane, wave);
+    };
+    __syncthreads();
+    if (wave == 0) { nodes(0); asm volatile("" ::: "memory"); nodes(1); }
+    __syncthreads();
+    rows(0);
+    lds_barrier();
+    RlBox Bc = box_of(0, 0);
+    issue(0, Bc, 0);
+    rl_wait();
+    lds_barrier();
+    int buf = 0;
+#pragma unroll 1
+    for (unsigned k = 0; k < n_it; k++) {
+        unsigned frame; int tx, ty;
+        const bool have = decode(k, frame, tx, ty);
+#pragma unroll 1
+        for (int half = 0; half < 2; half++) {
+            // the next half tile's box: start its copy into the other buffer, then this half tile's work
+            const RlBox Bn = half == 0 ? box_of(k, 1) : box_of(k + 1, 0);       // S.C[(k + 1) & 1] was completed before the barrier that ended half 0
+            issue(half == 0 ? k : k + 1, Bn, buf ^ 1);
+            if (half == 0) {
+                if (wave == (int)(k & 3)) nodes(k + 2);
+                rows(k + 1);
+            }
+            if (have) {
+                const int x0 = tx*RT + lx*PXT;
+                const Xf& xf = xfs[frame];
+                const SrcImg s{A.src + (size_t)frame*A.sframe, A.sw, A.sh, A.sstep};
+                const bool ok = S.ok[k & 3] != 0;
+                const int cb = (int)(k & 1);
+                const int X0q = Bc.on ? Bc.bx0 << INTER_BITS : 0, Y0q = Bc.on ? Bc.by0 << INTER_BITS : 0;
+                const double mu = ROUND_MAGIC - (double)X0q, mv = ROUND_MAGIC - (double)Y0q;
+                const uint32_t* box = (const uint32_t*)s_box[buf];
+                if (x0 < A.dw) {
+                    const RpFrameC fc = rp_frame_consts(xf);
+#pragma unroll 1
+                    for (int pass = 2*half; pass < 2*half + 2; pass++) {
+                        const int rr = pass*RT_RPP + ly, y = ty*RT + rr;
+                        if (y >= A.dh) break;
+                        int iu[PXT], iv[PXT], px[PXT][3];
+                        unsigned keep = 0;
+                        bool done = false;
+                        if (ok) {
+                            rp_coords(rp_row_consts(fc, y), S.C[cb][rr], z, x0, mu, mv, iu, iv);
+                            const unsigned rumax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
+                            const unsigned rvmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
+                            if (rumax < Bc.NXq && rvmax < Bc.NYq) {
+#pragma unroll
+                                for (int e = 0; e < PXT; e++) interp_u8_raw<HI16>(box, (unsigned)iu[e], (unsigned)iv[e], Bc.xoffB, px[e]);
+                                done = true;
+#ifdef GF_LB_STATS
+                                atomicAdd(&g_lb_stats[0], 1ull);
+#endif
+                            } else {
+#ifdef GF_LB_STATS
+                                atomicAdd(&g_lb_stats[1], 1ull);
+#endif
+#pragma unroll
+                                for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
+                            }
+                        } else {
+                            const Q5x4 q = coord_q5x4_cold(&xf, lk.k[0], lk.k[1], lk.k[2], lk.k[3], lk.bound, s_tab, y, x0);
+#pragma unroll
+                            for (int e = 0; e < PXT; e++) { iu[e] = q.iu[e]; iv[e] = q.iv[e]; }
+                        }
+                        if (!done) {
+                            const Px4 r = lb_remap4_cold<BORDER>(s.base, s.w, s.h, s.step, iu[0], iu[1], iu[2], iu[3], iv[0], iv[1], iv[2], iv[3], A.cval[0], A.cval[1], A.cval[2]);
+                            keep = r.keep;
+#pragma unroll
+                            for (int e = 0; e < PXT; e++) { px[e][0] = r.v[e][0]; px[e][1] = r.v[e][1]; px[e][2] = r.v[e][2]; }
+                        }
+                        uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
+                        store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
+                    }
+                }
+            }
+#ifdef GF_LB_STATS
+            if (tid == 0) atomicAdd(&g_lb_stats[Bc.on ? 2 : 3], 1ull);
+#endif
+            rl_wait();              // this wave's share of the copy has landed (and its stores have been acknowledged)
+            lds_barrier();          // everybody is done with `buf`; the other buffer is complete
+            buf ^= 1;
+            Bc = Bn;
+        }
+    }
+}
+#endif
+
 // K2 with RP coordinates (CV_16SC2 maps): one 64 x 64 tile per workgroup.
 __global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, const double* __restrict__ lens, const double* __restrict__ rp_tab, int w, int h,
                                                             uint8_t* map1, size_t m1step, uint8_t* map2, size_t m2step)
@@ -3036,6 +3259,17 @@ static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, i
         if (blocks == 0) blocks = NXCD;
         if (blocks > n_work) blocks = (unsigned)n_work;
         dim3 grid(blocks, 1);
+#ifdef GF_LB
+        if (ldsbox) {
+            unsigned lb_blocks = (unsigned)c->n_cu*wg_rp & ~(unsigned)(NXCD - 1);
+            if (lb_blocks == 0) lb_blocks = NXCD;
+            if (lb_blocks > n_work) lb_blocks = (unsigned)n_work;
+            dim3 lgrid(lb_blocks, 1), block(BLOCK);
+            if (border == GF_BORDER_CONSTANT)       hipLaunchKernelGGL((k_undistort_rotate_lb<GF_BORDER_CONSTANT>), lgrid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
+            else if (border == GF_BORDER_REPLICATE) hipLaunchKernelGGL((k_undistort_rotate_lb<GF_BORDER_REPLICATE>), lgrid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
+            else                                    hipLaunchKernelGGL((k_undistort_rotate_lb<GF_BORDER_TRANSPARENT>), lgrid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
+        } else
+#endif
         if (ldsbox) {
             dim3 block(BLOCK_RL);
             if (border == GF_BORDER_CONSTANT)       hipLaunchKernelGGL((k_undistort_rotate_rl<GF_BORDER_CONSTANT>), grid, block, 0, stream, A, (const Xf*)xf_dev, lens, lk, (const double*)c->rp_tab, tiles_pad, (unsigned)n_work);
@@ -3067,6 +3301,14 @@ static int launch_fused(const FusedEnv* c, int depth, const void* src, int sw, i
 }
 
 
+#if defined(GF_LB) && defined(GF_LB_STATS)
+GF_API int gf_debug_read_lb_stats(unsigned long long* out /* [4] */)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lb_stats), sizeof(unsigned long long)*4));
+    return GF_OK;
+}
+#endif
 #ifdef GF_TRACE_WG
 GF_API int gf_debug_read_wg_trace(unsigned long long* out /* [8192][3] */)      // tools/kbench prints the timeline
 {

@@ -22,6 +22,8 @@ for v in "$@"; do
     pairs_*) hipcc $F -DGF_COORD_PAIRS=1 -DGF_K1_WAVES=${v#pairs_} -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip ;;
     trace)    hipcc $F -DGF_TRACE_WG -o tools/_build/lib_trace.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;   # kbench --lib prints the workgroup timeline
     pf_*)     hipcc $F -DGF_RP_PREFETCH=${v#pf_} -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;     # K1 touching its rows <n> source rows ahead
+    lb_*)     hipcc $F -DGF_LB -DGF_LB_WAVES=${v#lb_} -o tools/_build/lib_$v.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;
+    lb)       hipcc $F -DGF_LB -o tools/_build/lib_lb.so gyroflow_amd/csrc/gfremap.hip gyroflow_amd/csrc/quat_host.cpp ;;      # mode rl (GF_K1=rl) runs the half-tile LDS-box kernel
     both)     hipcc $F -DGF_ABL_NOMATH -DGF_ABL_NOGATHER -o tools/_build/lib_both.so gyroflow_amd/csrc/gfremap.hip ;;
   esac
 done

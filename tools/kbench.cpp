@@ -112,6 +112,11 @@ int main(int argc, char** argv)
     std::vector<uint8_t> hd(dframe);
     CK(hipMemcpy(hd.data(), dst, dframe, hipMemcpyDeviceToHost));
     uint64_t cs = 0; for (size_t i = 0; i < dframe; i += 97) cs = cs*31 + hd[i];
+    typedef int (*stats_t)(unsigned long long*);
+    if (stats_t rd = (stats_t)dlsym(h, "gf_debug_read_lb_stats")) {       // tools build with -DGF_LB -DGF_LB_STATS
+        unsigned long long v[4];
+        if (rd(v) == 0) printf("lb stats: thread-passes from LDS %llu, from the frame %llu; half tiles with a box %llu, without %llu\n", v[0], v[1], v[2], v[3]);
+    }
     typedef int (*trace_t)(unsigned long long*);
     if (trace_t rd = (trace_t)dlsym(h, "gf_debug_read_wg_trace")) {        // tools build with -DGF_TRACE_WG: timeline of the last launch
         std::vector<unsigned long long> t(8192*3);
