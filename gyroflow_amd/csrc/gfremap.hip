@@ -1140,7 +1140,10 @@ __device__ __forceinline__ double rp_node_off(const double* __restrict__ rp_tab,
 // One wave, all 64 lanes: lane = a + 8 m evaluates node (column a, row m) of tile (tx, ty); offx / offy = rp_node_off(a / m).
 // Results: C2[m][a] (coefficient a of node row m), *okflag (every node passed), and with BOX the source positions of the
 // tile's rim nodes merged into boxslot[0..3] (min u, max u, min v, max v).
-template <bool BOX>
+#ifdef GF_LB
+__device__ __forceinline__ void lb_node_boxes(const Xf& xf, double X, double Y, double G, int a, int m, int all_ok, int* slot);
+#endif
+template <int BOX>          // 0: none; 1: the tile's box (RL); 2: the boxes of its two halves (LB, lb_node_boxes)
 __device__ __forceinline__ void rp_nodes(const Xf& xf, const LensK& lk, const double2* __restrict__ tab, double offx, double offy, int a, int m,
                                          int tx, int ty, double (*U)[RP_N], const RpConst& K, double (*C2)[RP_N], int* okflag, int* boxslot)
 {
@@ -1170,7 +1173,10 @@ __device__ __forceinline__ void rp_nodes(const Xf& xf, const LensK& lk, const do
     if (a == 0 && m == 0) *okflag = all_ok;
     // Box: the corner nodes and the end nodes of the two middle node rows (8 samples; LDS atomics from many lanes to one
     // address are serialised and cost more than the tile itself).  The margin of rl_box covers the bulge between them.
-    if (BOX && all_ok && (a == 0 || a == RP_N - 1) && (m == 0 || m == RP_N/2 - 1 || m == RP_N/2 || m == RP_N - 1)) {
+#ifdef GF_LB
+    if constexpr (BOX == 2) lb_node_boxes(xf, X, Y, G, a, m, all_ok, boxslot);
+#endif
+    if (BOX == 1 && all_ok && (a == 0 || a == RP_N - 1) && (m == 0 || m == RP_N/2 - 1 || m == RP_N/2 || m == RP_N - 1)) {
         const int su = __double2loint(__fma_rn(X*G, xf.f[0]*32.0, xf.c[0]*32.0) + ROUND_MAGIC) >> INTER_BITS;
         const int sv = __double2loint(__fma_rn(Y*G, xf.f[1]*32.0, xf.c[1]*32.0) + ROUND_MAGIC) >> INTER_BITS;
         atomicMin(&boxslot[0], su); atomicMax(&boxslot[1], su); atomicMin(&boxslot[2], sv); atomicMax(&boxslot[3], sv);
@@ -1405,7 +1411,7 @@ __global__ void __launch_bounds__(BLOCK, DEPTH == GF_DEPTH_U16 ? GF_RP_WAVES_U16
     };
     auto nodes = [&](unsigned k) {               // one wave
         unsigned frame; int tx, ty;
-        if (decode(k, frame, tx, ty)) rp_nodes<false>(xfs[frame], lk, s_tab, offx, offy, lane & 7, lane >> 3, tx, ty, S.U, S.K, S.C2[k & 1], &S.ok[k & 3], nullptr);
+        if (decode(k, frame, tx, ty)) rp_nodes<0>(xfs[frame], lk, s_tab, offx, offy, lane & 7, lane >> 3, tx, ty, S.U, S.K, S.C2[k & 1], &S.ok[k & 3], nullptr);
     };
     auto rows = [&](unsigned k) {                // all threads
         unsigned frame; int tx, ty;
@@ -1514,7 +1520,7 @@ __global__ void __launch_bounds__(BLOCK_RL, (GF_RL_WGS*(BLOCK_RL/64) + 3)/4) k_u
             int* slot = S.box[k & 3];
             if (lane < 4) slot[lane] = (lane & 1) ? INT_MIN : INT_MAX;     // same wave as the atomics: LDS keeps program order
             asm volatile("" ::: "memory");
-            rp_nodes<true>(xfs[frame], lk, tab, offx, offy, a, m, tx, ty, S.U, S.K, S.C2, &S.ok[k & 3], slot);
+            rp_nodes<1>(xfs[frame], lk, tab, offx, offy, a, m, tx, ty, S.U, S.K, S.C2, &S.ok[k & 3], slot);
             asm volatile("" ::: "memory");
             rp_rows(S.C2, S.K, a, m, RP_N, RT/RP_N, S.C[k % 3]);
             asm volatile("" ::: "memory");
@@ -1597,53 +1603,50 @@ __global__ void __launch_bounds__(BLOCK_RL, (GF_RL_WGS*(BLOCK_RL/64) + 3)/4) k_u
 // K1-LB (experiment, tools/build.sh lb): the RP kernel with its taps read from LDS.  Four waves, no producer: per HALF tile
 // (64 x 32 output pixels) the workgroup copies the source box of the next half tile into the other of two LDS buffers with
 // LDS-DMA (every wave issues its share, nothing waits for it by name) while all four waves compute the current half tile from
-// the current buffer; s_waitcnt vmcnt(0) + one barrier per half tile hand the buffers over.  The box of a half tile comes from
-// its row polynomials evaluated at the four corners (+- 2 positions); a thread whose taps are not all inside takes the
-// frame path, so results never depend on the estimate.  The lens table stays in global memory (only rp_nodes and the
-// per-pixel fallback read it): 2 x 11.5 KB of boxes + 14.7 KB of coefficients = 4 workgroups per CU.
+// the current buffer; s_waitcnt vmcnt(0) + one barrier per half tile hand the buffers over.  The boxes of a tile's two halves
+// come from the wave that runs its rp_nodes, two work items ahead: source positions of the rim nodes of the half's four node
+// rows and of the point between node rows 3 and 4 (tile row 31.5), merged with LDS atomics; +- 3 positions of margin.  A thread
+// whose taps are not all inside takes the general per-pixel path on the frame, so results never depend on the estimate.  The
+// lens table stays in global memory (only rp_nodes and the per-pixel fallback read it): 2 x 12 KB of boxes + 14.8 KB of
+// coefficients = 4 workgroups per CU.
 constexpr int LB_ROWS = 46;
 #ifdef GF_LB_STATS
-__device__ unsigned long long g_lb_stats[4];       // thread-passes from LDS, from the frame (box missed), boxes on, boxes off
+__device__ unsigned long long g_lb_stats[4];       // thread-passes from LDS, from the frame (box missed), half tiles with a box, without
 #endif
-__device__ __forceinline__ RlBox lb_box(const int (&e)[4], int sw, int sh)
+__device__ __forceinline__ RlBox lb_box(const int* slot, int sw, int sh)     // slot: min u, max u, min v, max v (wave-uniform values)
 {
+    const int4 e4 = *(const int4*)slot;
+    const int e0 = __builtin_amdgcn_readfirstlane(e4.x), e1 = __builtin_amdgcn_readfirstlane(e4.y);
+    const int e2 = __builtin_amdgcn_readfirstlane(e4.z), e3 = __builtin_amdgcn_readfirstlane(e4.w);
     RlBox B;
-    B.bx0 = max(e[0], 2) - 2; const int bx1 = min(e[1], sw - 4) + 2;
-    B.by0 = max(e[2], 2) - 2; const int by1 = min(e[3], sh - 4) + 2;
+    B.bx0 = max(e0, 3) - 3; const int bx1 = min(e1, sw - 5) + 3;
+    B.by0 = max(e2, 3) - 3; const int by1 = min(e3, sh - 5) + 3;
     B.bxB = ((unsigned)B.bx0*3u) & ~15u;
     B.xoffB = (unsigned)B.bx0*3u - B.bxB;
     B.nrows = by1 - B.by0 + 2;
     const long long nbytes = (long long)(bx1 + 2)*3 - (long long)B.bxB;
-    B.on = sw >= 4 && sh >= 4 && B.bx0 <= bx1 && B.by0 <= by1 && nbytes <= RL_PITCH && B.nrows <= LB_ROWS;
+    B.on = sw >= 8 && sh >= 8 && B.bx0 <= bx1 && B.by0 <= by1 && nbytes <= RL_PITCH && B.nrows <= LB_ROWS;
     B.NXq = B.on ? (unsigned)(bx1 - B.bx0 + 1) << INTER_BITS : 0u;
     B.NYq = B.on ? (unsigned)(by1 - B.by0 + 1) << INTER_BITS : 0u;
     return B;
 }
 
-// Source positions of the corners of tile rows r0 and r1 (all lanes compute; lanes 0..3 hold the corners), reduced to
-// wave-uniform min / max.
-__device__ __forceinline__ RlBox lb_box_of_rows(const double (*C)[RP_N], const RpFrameC& fc, int tx, int ty, int r0, int r1, int lane, int sw, int sh)
+// rp_nodes' wave, after the node values: half boxes of the tile into slot[0..3] (tile rows 0..31) and slot[4..7] (rows 32..63).
+// Node row m sits at tile row 31.5 + 32 cos((2m + 1) pi / 16): rows 4..7 are the upper half, 0..3 the lower one.
+__device__ __forceinline__ void lb_node_boxes(const Xf& xf, double X, double Y, double G, int a, int m, int all_ok, int* slot)
 {
-    const int r = (lane & 1) ? r1 : r0;
-    const int j = (lane & 2) ? RT - 1 : 0;
-    const double z = ((double)j - (RP_HALF - 0.5))*(1.0/RP_HALF);
-    const double2* c = (const double2*)C[r];
-    const double2 c0 = c[0], c1 = c[1], c2 = c[2], c3 = c[3];
-    double G = __fma_rn(c3.y, z, c3.x);
-    G = __fma_rn(G, z, c2.y); G = __fma_rn(G, z, c2.x); G = __fma_rn(G, z, c1.y); G = __fma_rn(G, z, c1.x);
-    G = __fma_rn(G, z, c0.y); G = __fma_rn(G, z, c0.x);
-    const RpRowC rc = rp_row_consts(fc, ty*RT + r);
-    const double dj = (double)(tx*RT + j);
-    const double X = __fma_rn(dj, rc.axp, rc.rxp), Y = __fma_rn(dj, rc.ayp, rc.ryp);
-    const double u32 = __fma_rn(X, G, rc.cx32), v32 = __fma_rn(Y, G, rc.cy32);
-    // clamp before the conversion: a wild value (a tile that is not ok) must not wrap
+    const double u32 = __fma_rn(X*G, xf.f[0]*32.0, xf.c[0]*32.0), v32 = __fma_rn(Y*G, xf.f[1]*32.0, xf.c[1]*32.0);
     const int su = (int)fmin(fmax(u32*(1.0/32), -1e6), 1e6), sv = (int)fmin(fmax(v32*(1.0/32), -1e6), 1e6);
-    int e[4];
-    const int u0 = __builtin_amdgcn_readlane(su, 0), u1 = __builtin_amdgcn_readlane(su, 1), u2 = __builtin_amdgcn_readlane(su, 2), u3 = __builtin_amdgcn_readlane(su, 3);
-    const int v0 = __builtin_amdgcn_readlane(sv, 0), v1 = __builtin_amdgcn_readlane(sv, 1), v2 = __builtin_amdgcn_readlane(sv, 2), v3 = __builtin_amdgcn_readlane(sv, 3);
-    e[0] = min(min(u0, u1), min(u2, u3)) - 1; e[1] = max(max(u0, u1), max(u2, u3)) + 1;      // (int) truncates towards zero: one more position each way
-    e[2] = min(min(v0, v1), min(v2, v3)) - 1; e[3] = max(max(v0, v1), max(v2, v3)) + 1;
-    return lb_box(e, sw, sh);
+    const int su_n = __shfl_down(su, 8), sv_n = __shfl_down(sv, 8);        // node row m + 1, same column
+    if (all_ok && (a == 0 || a == RP_N - 1)) {
+        int* h = slot + (m >= RP_N/2 ? 0 : 4);
+        atomicMin(&h[0], su - 1); atomicMax(&h[1], su + 1); atomicMin(&h[2], sv - 1); atomicMax(&h[3], sv + 1);     // (int) truncates towards zero
+        if (m == RP_N/2 - 1) {              // tile row 31.5: between this node row (37.7) and the next (25.3); goes into both halves
+            const int mu = (su + su_n) >> 1, mv = (sv + sv_n) >> 1;
+            atomicMin(&slot[0], mu - 1); atomicMax(&slot[1], mu + 2); atomicMin(&slot[2], mv - 1); atomicMax(&slot[3], mv + 2);
+            atomicMin(&slot[4], mu - 1); atomicMax(&slot[5], mu + 2); atomicMin(&slot[6], mv - 1); atomicMax(&slot[7], mv + 2);
+        }
+    }
 }
 
 // This wave's share of the copy of box B (groups of four rows: wave w takes groups w, w + 4, w + 8).
@@ -1664,25 +1667,12 @@ __device__ __forceinline__ void lb_issue(const RlBox& B, const uint8_t* __restri
     }
 }
 
-// Cold parts of the LB kernel as calls, so that their registers do not count against the half-tile loop.
+// rp_nodes as a call, so that its registers do not count against the half-tile loop
 __device__ __noinline__ void lb_nodes_cold(const Xf* xf, const LensK* lk, const double2* tab, const double* rp_tab, int lane, int tx, int ty,
-                                           RpShared* S, int c2buf, int okslot)
+                                           RpShared* S, int c2buf, int okslot, int* slot)
 {
-    const double offx = rp_node_off(rp_tab, lane & 7), offy = rp_node_off(rp_tab, lane >> 3);
-    rp_nodes<false>(*xf, *lk, tab, offx, offy, lane & 7, lane >> 3, tx, ty, S->U, S->K, S->C2[c2buf], &S->ok[okslot], nullptr);
+    rp_nodes<2>(*xf, *lk, tab, rp_node_off(rp_tab, lane & 7), rp_node_off(rp_tab, lane >> 3), lane & 7, lane >> 3, tx, ty, S->U, S->K, S->C2[c2buf], &S->ok[okslot], slot);
 }
-struct Px4 { int v[PXT][3]; unsigned keep; };
-template <int BORDER>
-__device__ __noinline__ Px4 lb_remap4_cold(const uint8_t* base, int sw, int sh, unsigned sstep, int iu0, int iu1, int iu2, int iu3, int iv0, int iv1, int iv2, int iv3,
-                                           int c0, int c1, int c2)
-{
-    const SrcImg s{base, sw, sh, sstep};
-    const int iu[PXT] = {iu0, iu1, iu2, iu3}, iv[PXT] = {iv0, iv1, iv2, iv3}, cval[3] = {c0, c1, c2};
-    Px4 r;
-    r.keep = remap4<GF_DEPTH_U8, BORDER, true>(s, iu, iv, cval, r.v);
-    return r;
-}
-
 #ifndef GF_LB_WAVES
 #define GF_LB_WAVES GF_RP_WAVES
 #endif
@@ -1692,8 +1682,8 @@ __global__ void __launch_bounds__(BLOCK, GF_LB_WAVES) k_undistort_rotate_lb(Rema
 {
     constexpr int DEPTH = GF_DEPTH_U8;
     constexpr bool HI16 = true;
-    static_assert(LB_ROWS*RL_PITCH % 16 == 0, "box buffers are uint4 arrays");
     __shared__ RpShared S;
+    __shared__ __attribute__((aligned(16))) int s_bx[4][8];     // [slot][half][min u, max u, min v, max v]
     __shared__ uint4 s_box[2][(LB_ROWS + 2)*RL_PITCH/16];       // groups of four rows: the last group may run two rows past LB_ROWS
     const double2* s_tab = (const double2*)lens;
     const int tid = (int)threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1710,47 +1700,47 @@ __global__ void __launch_bounds__(BLOCK, GF_LB_WAVES) k_undistort_rotate_lb(Rema
         frame = v / tiles_pad;
         return tile_of_padded_id(v - frame*tiles_pad, A.tiles_x, A.tiles_y, tx, ty);
     };
-    auto nodes = [&](unsigned k) {               // one wave
+    auto nodes = [&](unsigned k) {               // one wave: coefficients, flag and half boxes of work item k
         unsigned frame; int tx, ty;
-        if (decode(k, frame, tx, ty)) lb_nodes_cold(&xfs[frame], &lk, s_tab, rp_tab, lane, tx, ty, &S, (int)(k & 1), (int)(k & 3));
-    };
-    auto rows = [&](unsigned k) {                // all threads
-        unsigned frame; int tx, ty;
-        if (decode(k, frame, tx, ty)) rp_rows(S.C2[k & 1], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[k & 1]);
-    };
-    auto box_of = [&](unsigned k, int half) -> RlBox {      // wave-uniform; off when the item does not exist or its tile is not ok
-        RlBox B; B.on = false; B.bx0 = B.by0 = 0; B.NXq = B.NYq = 0; B.bxB = 0; B.xoffB = 0; B.nrows = 0;
-        unsigned frame; int tx, ty;
-        if (decode(k, frame, tx, ty) && S.ok[k & 3] != 0)
-            B = lb_box_of_rows(S.C[k & 1], rp_frame_consts(xfs[frame]), tx, ty, half*(RT/2), half*(RT/2) + RT/2 - 1, lane, A.sw, A.sh);
-        return B;
-    };
-    auto issue = [&](unsigned k, const RlBox& B, int buf) {
-        unsigned frame; int tx, ty;
-        if (B.on && decode(k, frame, tx, ty)) lb_issue(B, A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[buf], lane, wave);
+        int* slot = s_bx[k & 3];
+        if (lane < 8) slot[lane] = (lane & 1) ? INT_MIN : INT_MAX;      // LDS operations of one wave execute in program order
+        asm volatile("" ::: "memory");
+#ifndef GF_LB_NONODES     /* register-count probe only */
+        if (decode(k, frame, tx, ty))
+            lb_nodes_cold(&xfs[frame], &lk, s_tab, rp_tab, lane, tx, ty, &S, (int)(k & 1), (int)(k & 3), slot);
+#endif
     };
     __syncthreads();
     if (wave == 0) { nodes(0); asm volatile("" ::: "memory"); nodes(1); }
     __syncthreads();
-    rows(0);
-    lds_barrier();
-    RlBox Bc = box_of(0, 0);
-    issue(0, Bc, 0);
+    {
+        unsigned f0; int a0, b0;
+        if (decode(0, f0, a0, b0)) rp_rows(S.C2[0], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[0]);
+    }
+    // work item k and k + 1 as decoded once: (have, frame, tx, ty)
+    unsigned frame = 0, frame1 = 0; int tx = 0, ty = 0, tx1 = 0, ty1 = 0;
+    bool have = decode(0, frame, tx, ty), have1 = false;
+    RlBox Bc; Bc.on = false; Bc.bx0 = Bc.by0 = 0; Bc.NXq = Bc.NYq = 0; Bc.bxB = 0; Bc.xoffB = 0; Bc.nrows = 0;
+    if (have && S.ok[0] != 0) Bc = lb_box(&s_bx[0][0], A.sw, A.sh);
+    if (have) lb_issue(Bc, A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[0], lane, wave);
     rl_wait();
     lds_barrier();
     int buf = 0;
 #pragma unroll 1
     for (unsigned k = 0; k < n_it; k++) {
-        unsigned frame; int tx, ty;
-        const bool have = decode(k, frame, tx, ty);
+        have1 = decode(k + 1, frame1, tx1, ty1);
 #pragma unroll 1
         for (int half = 0; half < 2; half++) {
             // the next half tile's box: start its copy into the other buffer, then this half tile's work
-            const RlBox Bn = half == 0 ? box_of(k, 1) : box_of(k + 1, 0);       // S.C[(k + 1) & 1] was completed before the barrier that ended half 0
-            issue(half == 0 ? k : k + 1, Bn, buf ^ 1);
+            RlBox Bn; Bn.on = false; Bn.bx0 = Bn.by0 = 0; Bn.NXq = Bn.NYq = 0; Bn.bxB = 0; Bn.xoffB = 0; Bn.nrows = 0;
             if (half == 0) {
+                if (have && S.ok[k & 3] != 0) Bn = lb_box(&s_bx[k & 3][4], A.sw, A.sh);
+                if (have) lb_issue(Bn, A.src + (size_t)frame*A.sframe, A.sstep, limit, s_box[buf ^ 1], lane, wave);
                 if (wave == (int)(k & 3)) nodes(k + 2);
-                rows(k + 1);
+                if (have1) rp_rows(S.C2[(k + 1) & 1], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[(k + 1) & 1]);
+            } else {
+                if (have1 && S.ok[(k + 1) & 3] != 0) Bn = lb_box(&s_bx[(k + 1) & 3][0], A.sw, A.sh);
+                if (have1) lb_issue(Bn, A.src + (size_t)frame1*A.sframe, A.sstep, limit, s_box[buf ^ 1], lane, wave);
             }
             if (have) {
                 const int x0 = tx*RT + lx*PXT;
@@ -1771,7 +1761,7 @@ __global__ void __launch_bounds__(BLOCK, GF_LB_WAVES) k_undistort_rotate_lb(Rema
                         unsigned keep = 0;
                         bool done = false;
                         if (ok) {
-                            rp_coords(rp_row_consts(fc, y), S.C[cb][rr], z, x0, mu, mv, iu, iv);
+                            rp_coords(rp_row_consts(fc, y), S.C[cb][rr], z, x0, mu, mv, iu, iv);         // relative to the box
                             const unsigned rumax = max(max((unsigned)iu[0], (unsigned)iu[1]), max((unsigned)iu[2], (unsigned)iu[3]));
                             const unsigned rvmax = max(max((unsigned)iv[0], (unsigned)iv[1]), max((unsigned)iv[2], (unsigned)iv[3]));
                             if (rumax < Bc.NXq && rvmax < Bc.NYq) {
@@ -1782,22 +1772,28 @@ __global__ void __launch_bounds__(BLOCK, GF_LB_WAVES) k_undistort_rotate_lb(Rema
                                 atomicAdd(&g_lb_stats[0], 1ull);
 #endif
                             } else {
+#pragma unroll
+                                for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
 #ifdef GF_LB_STATS
                                 atomicAdd(&g_lb_stats[1], 1ull);
 #endif
-#pragma unroll
-                                for (int e = 0; e < PXT; e++) { iu[e] += X0q; iv[e] += Y0q; }
                             }
                         } else {
                             const Q5x4 q = coord_q5x4_cold(&xf, lk.k[0], lk.k[1], lk.k[2], lk.k[3], lk.bound, s_tab, y, x0);
 #pragma unroll
                             for (int e = 0; e < PXT; e++) { iu[e] = q.iu[e]; iv[e] = q.iv[e]; }
                         }
-                        if (!done) {
-                            const Px4 r = lb_remap4_cold<BORDER>(s.base, s.w, s.h, s.step, iu[0], iu[1], iu[2], iu[3], iv[0], iv[1], iv[2], iv[3], A.cval[0], A.cval[1], A.cval[2]);
-                            keep = r.keep;
+                        if (!done) {            // the general per-pixel path on the frame (a call per pixel: rare)
+#pragma unroll 1
+                            for (int e = 0; e < PXT; e++) {
+                                const int sx = (int)(int16_t)(iu[e] >> INTER_BITS), sy = (int)(int16_t)(iv[e] >> INTER_BITS);   // Q1: wrapping cast
+                                const Px3 o = bilinear_px<DEPTH, BORDER>(s, sx, sy, (iv[e] & 31)*32 + (iu[e] & 31), A.cval[0], A.cval[1], A.cval[2]);
+                                const int c0 = o.c0 << 16, c1 = o.c1 << 16, c2 = o.c2 << 16;
+                                // px[e] with a dynamic e would go through memory: select into the registers instead
 #pragma unroll
-                            for (int e = 0; e < PXT; e++) { px[e][0] = r.v[e][0]; px[e][1] = r.v[e][1]; px[e][2] = r.v[e][2]; }
+                                for (int j = 0; j < PXT; j++) if (j == e) { px[j][0] = c0; px[j][1] = c1; px[j][2] = c2; }
+                                if (!o.ok) keep |= 1u << e;
+                            }
                         }
                         uint8_t* drow = A.dst + (size_t)frame*A.dframe + (size_t)y*A.dstep;
                         store_px<DEPTH, HI16>(drow, x0, A.dw, px, keep, A.dst_vec_ok);
@@ -1807,11 +1803,16 @@ __global__ void __launch_bounds__(BLOCK, GF_LB_WAVES) k_undistort_rotate_lb(Rema
 #ifdef GF_LB_STATS
             if (tid == 0) atomicAdd(&g_lb_stats[Bc.on ? 2 : 3], 1ull);
 #endif
-            rl_wait();              // this wave's share of the copy has landed (and its stores have been acknowledged)
+            // this wave's share of the copy must have landed.  Vector-memory operations retire in order, and the copy was issued
+            // before this half tile's two stores: when both were issued (a tile that lies fully inside the output) it is enough to
+            // wait for everything but the two youngest operations, so that the stores' acknowledgements are not waited for
+            if (have && tx*RT + RT <= A.dw && ty*RT + half*(RT/2) + RT/2 <= A.dh) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else rl_wait();
             lds_barrier();          // everybody is done with `buf`; the other buffer is complete
             buf ^= 1;
             Bc = Bn;
         }
+        have = have1; frame = frame1; tx = tx1; ty = ty1;
     }
 }
 #endif
@@ -1828,7 +1829,7 @@ __global__ void __launch_bounds__(BLOCK) k_fisheye_maps_rp(Xf xf, LensK lk, cons
     const int lx = tid & (RT_TPR - 1), ly = tid / RT_TPR;
     const int tx = blockIdx.x, ty = blockIdx.y;
     __syncthreads();
-    if (tid < 64) rp_nodes<false>(xf, lk, s_tab, rp_node_off(rp_tab, lane & 7), rp_node_off(rp_tab, lane >> 3), lane & 7, lane >> 3, tx, ty, S.U, S.K, S.C2[0], &S.ok[0], nullptr);
+    if (tid < 64) rp_nodes<0>(xf, lk, s_tab, rp_node_off(rp_tab, lane & 7), rp_node_off(rp_tab, lane >> 3), lane & 7, lane >> 3, tx, ty, S.U, S.K, S.C2[0], &S.ok[0], nullptr);
     __syncthreads();
     rp_rows(S.C2[0], S.K, tid & 7, tid >> 3, RT/2, 2, S.C[0]);
     __syncthreads();
@@ -1975,7 +1976,7 @@ __global__ void __launch_bounds__(BLOCK) k_undistort_rotate_blend_rp(RemapArgs A
 #pragma unroll 1
     for (int b0 = 0; b0 < n_blend; b0 += BLOCK/64) {
         if (b0 + wave < n_blend)
-            rp_nodes<false>(xfs[g*frames_per_group + b0 + wave], lk, s_tab, offx, offy, lane & 7, lane >> 3, tx, ty, U[wave], K, C2[wave], &okf[b0 + wave], nullptr);
+            rp_nodes<0>(xfs[g*frames_per_group + b0 + wave], lk, s_tab, offx, offy, lane & 7, lane >> 3, tx, ty, U[wave], K, C2[wave], &okf[b0 + wave], nullptr);
         __syncthreads();
         for (int j = 0; j < BLOCK/64 && b0 + j < n_blend; j++) rp_rows(C2[j], K, tid & 7, tid >> 3, RT/2, 2, C[b0 + j]);
         __syncthreads();
@@ -2527,7 +2528,7 @@ __global__ void __launch_bounds__(BLOCK, 4) k_undistort_rotate_superview(RemapAr
             if ((GF_FS_ABL & 1) && t9 != 4) { if (lane == 0) S.ok[t9] = -1; continue; }
             const int ntx = tx + t9 % 3 - 1, nty = ty + t9/3 - 1;
             if (ntx < 0 || ntx >= A.tiles_x || nty < 0 || nty >= A.tiles_y) { if (lane == 0) S.ok[t9] = -1; continue; }
-            rp_nodes<false>(xf, lk, tab, offx, offy, lane & 7, lane >> 3, ntx, nty, S.U[wave], S.K, S.C2[t9], &S.ok[t9], nullptr);
+            rp_nodes<0>(xf, lk, tab, offx, offy, lane & 7, lane >> 3, ntx, nty, S.U[wave], S.K, S.C2[t9], &S.ok[t9], nullptr);
             asm volatile("" ::: "memory");
         }
         lds_barrier();
